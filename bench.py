@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Benchmark of the FDK hot path (weight -> ramp row filter -> backproject) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Metric (BASELINE.json): GVoxel-updates/s = voxels x projections / seconds / 1e9, whole job over all N GPUs.
+A step is one pass of the hot path over one batch of `--batch` synthetic projections: for each projection a
+device copy of the raw frame into the work buffer (stands in for the upload), paris::weight, paris::filter,
+paris::backproject into the rank's z-slab. Inputs are resident in HBM before the timed region starts.
+
+Workloads (BASELINE.json configs; geometry per SURVEY.md 8d: l_px 0.2 mm, d_so = d_od = 500 mm, no offsets):
+  c3 (default)  2048^3 volume, 1440 projections @ 2048x2048 fp32. N = 1: the whole volume on one GPU (config 3,
+                the HBM-roofline run); N > 1: the same volume in N z-slabs, one per GPU (config 4 at N = 8):
+                total work is fixed, so "scaling" is "strong". No collective on the data path.
+  c2            1024^3 volume, 720 projections @ 1024x1024.
+  c1            256^3 volume, 360 projections @ 512x512.
+
+The JSON line also carries
+  roofline      for the dominant kernel (backprojection): algorithmic bytes per launch (8 B per voxel-update +
+                one pass over the projection) / average launch duration from HIP events recorded on the launch
+                stream inside the timed region, against the 8 TB/s HBM3E peak;
+  cpu_baseline  the CPU oracle (this repo's restatement of the reference's OpenMP path, "port") timed on this
+                host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    "c3": dict(n_row=2048, n_col=2048, n_proj=1440, vol=(2048, 2048, 2048),
+               name="2048^3 volume, 1440 projections @ 2048x2048 fp32"),
+    "c2": dict(n_row=1024, n_col=1024, n_proj=720, vol=(1024, 1024, 1024),
+               name="1024^3 volume, 720 projections @ 1024x1024 fp32"),
+    "c1": dict(n_row=512, n_col=512, n_proj=360, vol=(256, 256, 256),
+               name="256^3 volume, 360 projections @ 512x512 fp32"),
+}
+
+
+def geometry(B, w):
+    det = B.DetectorGeometry(w["n_row"], w["n_col"], 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 360.0 / w["n_proj"])
+    nat = B.calculate_volume_geometry(det)
+    dx, dy, dz = w["vol"]
+    import numpy as np
+    l_vx = float(np.float32(nat.l_vx_x) * np.float32(w["n_row"]) / np.float32(dx))
+    return det, B.VolumeGeometry(dx, dy, dz, l_vx, l_vx, l_vx)
+
+
+def cpu_baseline(w, budget_s):
+    """Times the oracle's backprojection on this host's cores: the workload's geometry, a slab of `slices`
+    central slices, as many projections as fit the time budget."""
+    import numpy as np
+
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    O.lib().po_set_num_threads(cores)
+    det = O.DetectorGeometry(w["n_row"], w["n_col"], 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 360.0 / w["n_proj"])
+    nat = O.calculate_volume_geometry(det)
+    dx, dy, dz = w["vol"]
+    l_vx = float(np.float32(nat.l_vx_x) * np.float32(w["n_row"]) / np.float32(dx))
+    vg = O.VolumeGeometry(dx, dy, dz, l_vx, l_vx, l_vx)
+    slices = max(1, min(dz, (64 << 20) // (dx * dy)))  # ~64 Mi voxels per projection
+    z0 = (dz - slices) // 2
+    vol = np.zeros((slices, dy, dx), np.float32)
+    fs = O.filter_size(det.n_row)
+    k = O.make_filter(fs, det.l_px_row)
+    t_w = t_f = t_b = 0.0
+    n = 0
+    t_start = time.perf_counter()
+    while n < w["n_proj"]:
+        p = O.lcg_projection(det.n_row, det.n_col, n)
+        t0 = time.perf_counter()
+        O.weight(p, det)
+        t1 = time.perf_counter()
+        O.apply_filter(p, k, fs)
+        t2 = time.perf_counter()
+        s, c, ds, dt = O.backproject_constants(det, n)
+        O.backproject(vol, p, z0, det, vg, s, c, ds, dt)
+        t3 = time.perf_counter()
+        t_w += t1 - t0
+        t_f += t2 - t1
+        t_b += t3 - t2
+        n += 1
+        if n >= 2 and time.perf_counter() - t_start > budget_s:
+            break
+    updates = float(slices) * dx * dy * n
+    return {
+        "value": updates / t_b / 1e9, "unit": "GVoxel-updates/s", "cores": cores, "kind": "port",
+        "sample": "%s geometry, %d central slices (z %d..%d) x %d projections; backproject %.2f s "
+                  "(weight %.2f s, filter %.2f s not in value)" % (w["name"], slices, z0, z0 + slices - 1, n,
+                                                                    t_b, t_w, t_f),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--batch", type=int, default=8, help="projections per step")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline (0 disables)")
+    ap.add_argument("--vx", type=int, default=0)
+    ap.add_argument("--unroll", type=int, default=0)
+    ap.add_argument("--tz", type=int, default=0)
+    ap.add_argument("--lds-bytes", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N > 1 through torch.distributed.run)"
+                         % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible -- the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    from paris_amd import backend as B
+    from paris_amd import sharding
+
+    w = WORKLOADS[args.workload]
+    det, vol_geo = geometry(B, w)
+    info = sharding.make_subvolume_info(vol_geo, world)  # one z-slab per rank
+    z_first, z_count = sharding.slab_of_task(info, rank)
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    be = B.Backend(local_rank, stream=stream, synchronous=False)
+    be.set_backproject_tuning(args.vx, args.unroll, args.tz, args.lds_bytes)
+
+    n_row, n_col = w["n_row"], w["n_col"]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(12345 + rank)
+    raw = torch.rand((args.batch, n_col, n_row), generator=gen, device=dev, dtype=torch.float32)
+    work = torch.empty_like(raw)
+    vol = torch.zeros((z_count, vol_geo.dim_y, vol_geo.dim_x), device=dev, dtype=torch.float32)
+    d_vol = be.wrap_volume(vol.data_ptr(), vol_geo.dim_x, vol_geo.dim_y, z_count, owner=vol)
+    pitch = work.stride(1) * 4
+    projs = [be.wrap_projection(work[b].data_ptr(), pitch, n_row, n_col, owner=work) for b in range(args.batch)]
+
+    def step(s):
+        for b in range(args.batch):
+            p = projs[b]
+            p.idx = (s * args.batch + b) % w["n_proj"]
+            work[b].copy_(raw[b], non_blocking=True)                          # stands in for the upload
+            B.weight(be, p, det)                                              # src/main.cpp:102
+            B.filter(be, p, det)                                              # :103
+            B.backproject(be, p, d_vol, z_first, det, vol_geo, False, False, None)  # :104
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    for s in range(args.warmup):
+        step(s)
+    torch.cuda.synchronize()
+    be.backproject_timing_arm(min(65536, max(1, args.steps * args.batch)))
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(args.warmup + s)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = be.backproject_timing_collect()
+    voxels_rank = float(z_count) * vol_geo.dim_x * vol_geo.dim_y
+    voxels_all = float(vol_geo.dim_z) * vol_geo.dim_x * vol_geo.dim_y
+    updates_all = voxels_all * args.batch * args.steps
+
+    if rank == 0:
+        avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        algo_bytes = 8.0 * voxels_rank + 4.0 * n_row * n_col  # per launch: RMW of the slab + one projection pass
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "GVoxel-updates/s (voxels x projections / s), FDK hot path weight+filter+backproject",
+            "value": updates_all / elapsed / 1e9,
+            "unit": "GVoxel-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (uniform noise projections generated on device; zero-initialised volume)",
+            "config": {
+                "workload": w["name"] + (", 1 GPU" if world == 1 else ", %d z-slabs on %d GPUs" % (world, world)),
+                "projections_per_step": args.batch,
+                "slab_per_gpu": [vol_geo.dim_x, vol_geo.dim_y, z_count],
+                "parallelism": "z-slab per GPU, no collective on the data path",
+                "backproject_kernel_ms": avg_ms,
+                "backproject_GVox_per_s_per_gpu": voxels_rank / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "bp_tile_kernel (one projection per launch, 8 B per voxel-update)",
+                "launches_timed": len(kernel_ms),
+            },
+        }
+        if world == 1 and args.cpu_budget > 0:
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+
+    be.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,222 @@
+/*
+ * paris_hip.h -- C ABI of the MI355X (gfx950) backend for the hzdr/PARIS FDK hot path.
+ *
+ * This is the drop-in boundary. PARIS selects a backend at compile time through a namespace alias
+ * (src/backend.h:26-47); a backend is a set of types plus 14 free functions (src/generic/backend.h:54-88,
+ * src/openmp/backend.h:42-89, src/cuda/backend.h:50-103). The C++ header paris_amd/host/hip/backend.h
+ * implements that surface (namespace paris::hip) on top of the entry points below; INTEGRATION.md shows
+ * the `#elif defined(PARIS_ENABLE_HIP)` arm a maintainer adds to src/backend.h.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns 0 (PARIS_HIP_SUCCESS) or a non-zero status
+ *     (hipError_t values are passed through, library-specific ones start at 10000); no exceptions cross
+ *     this boundary. paris_hip_strerror() turns a status into text. The C++ wrappers translate a non-zero
+ *     status into paris::stage_runtime_error / stage_construction_error (src/exception.h:31-41).
+ *   - a paris_hip_ctx replaces every function-local `static` / `thread_local static` of the reference
+ *     (src/weighting.cpp:37-42, src/filtering.cpp:37-42, src/backprojection.cpp:49-50,
+ *     src/cuda/filtering.cu:189-240, src/cuda/backprojection.cu:160-185): device, stream, FFT scratch.
+ *     One ctx per device and host thread; a ctx is not thread-safe (reference contract "thread == device",
+ *     src/main.cpp:87,157-167).
+ *   - all device work is enqueued on the ctx stream. Calls are asynchronous unless the ctx was created with
+ *     PARIS_HIP_CTX_SYNCHRONOUS, in which case every call synchronises the stream before it returns, as
+ *     the reference's CUDA backend does (src/cuda/weighting.cu:72, filtering.cu:260, backprojection.cu:236).
+ *   - projections are row-major `buf[s + t * pitch/4]`, s in [0, dim_x) fastest (src/openmp/weighting.cpp:41);
+ *     `pitch` is the row stride in BYTES (>= dim_x*4, multiple of 4), the same meaning as
+ *     cuda::projection_device_buffer_type::pitch() (src/cuda/weighting.cu:43-45).
+ *     Volumes are dense `buf[k + l*dim_x + m*dim_x*dim_y]` (src/openmp/backprojection.cpp:102) with 64-bit
+ *     indexing (the reference's 32-bit arithmetic, SURVEY.md Q3, is not reproduced).
+ */
+#ifndef PARIS_HIP_H_
+#define PARIS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PARIS_HIP_SUCCESS 0
+#define PARIS_HIP_ERROR_INVALID_ARGUMENT 10001
+#define PARIS_HIP_ERROR_NO_DEVICE 10002
+#define PARIS_HIP_ERROR_UNSUPPORTED 10003
+
+/* ctx flags */
+#define PARIS_HIP_CTX_DEFAULT 0u
+#define PARIS_HIP_CTX_SYNCHRONOUS 1u /* sync the stream before every call returns (reference behaviour) */
+
+/* src/geometry.h:30-46, field for field */
+typedef struct paris_detector_geometry {
+    uint32_t n_row;   /* pixels per row */
+    uint32_t n_col;   /* pixels per column */
+    float l_px_row;   /* pixel size, horizontal [mm] */
+    float l_px_col;   /* pixel size, vertical [mm] */
+    float delta_s;    /* horizontal offset [px] */
+    float delta_t;    /* vertical offset [px] */
+    float d_so;       /* source -> object */
+    float d_od;       /* object -> detector */
+    float delta_phi;  /* angle step [deg] */
+} paris_detector_geometry;
+
+/* src/geometry.h:48-57 */
+typedef struct paris_volume_geometry {
+    uint32_t dim_x, dim_y, dim_z;
+    float l_vx_x, l_vx_y, l_vx_z;
+} paris_volume_geometry;
+
+/* src/geometry.h:59-69 */
+typedef struct paris_subvolume_geometry {
+    uint32_t dim_x, dim_y, dim_z;
+    uint32_t remainder;
+} paris_subvolume_geometry;
+
+/* src/region_of_interest.h:30-38 */
+typedef struct paris_region_of_interest {
+    uint32_t x1, x2, y1, y2, z1, z2;
+} paris_region_of_interest;
+
+/* src/subvolume_information.h:30-34 */
+typedef struct paris_subvolume_info {
+    paris_subvolume_geometry geo;
+    int num;
+} paris_subvolume_info;
+
+typedef struct paris_hip_ctx paris_hip_ctx;
+
+/* ---- device management: backend::get_devices / set_device (src/cuda/device.cpp:31-47,
+ *      src/openmp/backend.h:87-89) -------------------------------------------------------------------- */
+int paris_hip_device_count(int* count);
+
+/* Creates the per-device state. `stream` is a hipStream_t to enqueue on (e.g. the caller's torch stream),
+ * or NULL to let the ctx create and own a non-blocking stream. Replaces set_device + all thread_local
+ * statics. */
+int paris_hip_ctx_create(int device, void* stream, unsigned flags, paris_hip_ctx** out);
+int paris_hip_ctx_destroy(paris_hip_ctx* ctx);
+/* synchronize_stream (src/cuda/stream.cpp) */
+int paris_hip_ctx_synchronize(paris_hip_ctx* ctx);
+/* the hipStream_t the ctx enqueues on */
+void* paris_hip_ctx_stream(paris_hip_ctx* ctx);
+
+/* ---- memory: make_projection_device / make_volume_device / copy_h2d / copy_d2h
+ *      (src/cuda/memory.cpp:33-102, src/openmp/memory.cpp:33-79) ------------------------------------- */
+/* device projection, rows padded to a 256-byte multiple; *pitch receives the row stride in bytes */
+int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, float** d_ptr, size_t* pitch);
+/* device volume, zero-filled (make_volume_device semantics: src/openmp/memory.cpp:46-47) */
+int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, float** d_ptr);
+int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr);
+/* pinned host memory for projection/volume host buffers (cuda: pinned_host_ptr) */
+int paris_hip_malloc_host(paris_hip_ctx* ctx, size_t bytes, void** h_ptr);
+int paris_hip_free_host(paris_hip_ctx* ctx, void* h_ptr);
+/* 2-D copies, pitches in bytes; projection rows are dim_x floats */
+int paris_hip_memcpy_projection_h2d(paris_hip_ctx* ctx, float* d_dst, size_t d_pitch, const float* h_src,
+                                    size_t h_pitch, uint32_t dim_x, uint32_t dim_y);
+int paris_hip_memcpy_projection_d2h(paris_hip_ctx* ctx, float* h_dst, size_t h_pitch, const float* d_src,
+                                    size_t d_pitch, uint32_t dim_x, uint32_t dim_y);
+int paris_hip_memcpy_volume_h2d(paris_hip_ctx* ctx, float* d_dst, const float* h_src, uint32_t dim_x,
+                                uint32_t dim_y, uint32_t dim_z);
+int paris_hip_memcpy_volume_d2h(paris_hip_ctx* ctx, float* h_dst, const float* d_src, uint32_t dim_x,
+                                uint32_t dim_y, uint32_t dim_z);
+int paris_hip_memset_volume(paris_hip_ctx* ctx, float* d_ptr, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z);
+
+/* ---- make_subvolume_information (src/cuda/subvolume_information.cpp:63-118) ---------------------- */
+/* Splits dim_z into `num` slabs (+ remainder on the last) so that one slab plus `proj_slots` projections
+ * fits in the free memory of each of `n_devices` devices. n_devices <= 0 means all visible devices. */
+int paris_hip_make_subvolume_information(const paris_volume_geometry* vol_geo,
+                                         const paris_detector_geometry* det_geo, int n_devices,
+                                         paris_subvolume_info* out);
+
+/* ---- weighting: backend::weight (src/openmp/weighting.cpp:32-57, src/cuda/weighting.cu:62-73) ---- */
+/* p[t][s] *= d_sd / sqrt(d_sd^2 + h_s^2 + v_t^2), h_s = l_px_row/2 + s*l_px_row + h_min, v_t likewise.
+ * IEEE sqrt and divide: bit-identical to the OpenMP backend. */
+int paris_hip_weight(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y, float h_min,
+                     float v_min, float d_sd, float l_px_row, float l_px_col);
+
+/* ---- filtering: backend::make_filter / apply_filter (src/openmp/filtering.cpp:139-219,
+ *      src/cuda/filtering.cu:172-261) --------------------------------------------------------------- */
+/* K = tau * |rFFT_size(r)| with r the band-limited ramp of src/openmp/filtering.cpp:52-73. *d_k receives a
+ * device buffer of size/2+1 floats (the reference stores the same value in re and im of a complex; the
+ * product is identical) owned by the caller: release with paris_hip_free. size must be a
+ * power of two in [8, 16384]. */
+int paris_hip_make_filter(paris_hip_ctx* ctx, uint32_t size, float tau, float** d_k);
+/* In place, per detector row: zero-pad to filter_size, FFT, multiply by K, inverse FFT, keep the first dim_x
+ * samples, divide by filter_size. n_col is the number of rows (== dim_y; kept because the reference passes
+ * it, src/filtering.cpp:44). */
+int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                           const float* d_k, uint32_t filter_size, uint32_t n_col);
+
+/* ---- backprojection: backend::backproject (src/openmp/backprojection.cpp:156-199,
+ *      src/cuda/backprojection.cu:133-243) ---------------------------------------------------------- */
+/* Adds one filtered projection into the (sub)volume d_v of v_dim_x*v_dim_y*v_dim_z voxels whose first
+ * slice is global slice v_offset (+ roi->z1 when enable_roi). Voxel-driven, bilinear, zero unless all four
+ * neighbours lie inside the detector (OpenMP rule, src/openmp/backprojection.cpp:52-84); every fp32
+ * operation is rounded once in the reference's order, so the result is bit-identical to the OpenMP
+ * backend's for the same input. sin/cos/delta_s/delta_t are what the wrapper src/backprojection.cpp:49-68
+ * derives (delta_* in mm). */
+int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, uint32_t p_dim_x,
+                          uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z,
+                          uint32_t v_offset, const paris_detector_geometry* det_geo,
+                          const paris_volume_geometry* vol_geo, int enable_roi,
+                          const paris_region_of_interest* roi, float sin_phi, float cos_phi, float delta_s,
+                          float delta_t);
+
+/* Extension (no reference counterpart): backprojects n_proj projections in one launch; projection i is at
+ * d_p + i * p_stride_bytes. The per-voxel sum is accumulated in projection order, so the result is
+ * bit-identical to n_proj successive paris_hip_backproject calls while the volume is read and written
+ * once per `batch` projections instead of once per projection. */
+int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, size_t p_stride_bytes,
+                                uint32_t n_proj, uint32_t p_dim_x, uint32_t p_dim_y, float* d_v,
+                                uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
+                                const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo,
+                                int enable_roi, const paris_region_of_interest* roi, const float* sin_phi,
+                                const float* cos_phi, float delta_s, float delta_t);
+
+/* ---- stage wrappers and geometry (host code of the hot path) ----------------------------------------
+ * The reference derives the kernels' scalar arguments in backend-neutral wrappers and caches them in
+ * function-local statics; these entry points restate them per call (no statics). */
+/* calculate_volume_geometry (src/geometry.cpp:36-84) */
+int paris_hip_calculate_volume_geometry(const paris_detector_geometry* det_geo, paris_volume_geometry* out);
+/* apply_roi (src/geometry.cpp:86-130); an invalid ROI returns the input geometry, as the reference does */
+int paris_hip_apply_roi(const paris_volume_geometry* vol_geo, const paris_region_of_interest* roi,
+                        paris_volume_geometry* out);
+/* paris::weight (src/weighting.cpp:32-45): derives h_min, v_min, d_sd and calls paris_hip_weight */
+int paris_hip_stage_weight(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                           const paris_detector_geometry* det_geo);
+/* filter_size = 2 * 2^ceil(log2(n_row)) (src/filtering.cpp:37) */
+uint32_t paris_hip_filter_size(uint32_t n_row);
+/* paris::filter (src/filtering.cpp:32-45): builds K once per ctx, then paris_hip_apply_filter */
+int paris_hip_stage_filter(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                           const paris_detector_geometry* det_geo);
+/* angle of projection idx -> sin/cos on the host in fp32 (src/backprojection.cpp:52-63) */
+int paris_hip_stage_angle(const paris_detector_geometry* det_geo, uint32_t idx, int enable_angles, float phi,
+                          float* sin_phi, float* cos_phi);
+/* paris::backproject (src/backprojection.cpp:37-69): p_idx / p_phi are projection::idx / projection::phi */
+int paris_hip_stage_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, uint32_t p_dim_x,
+                                uint32_t p_dim_y, uint32_t p_idx, float p_phi, float* d_v, uint32_t v_dim_x,
+                                uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
+                                const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo,
+                                int enable_angles, int enable_roi, const paris_region_of_interest* roi);
+
+/* ---- diagnostics ---------------------------------------------------------------------------------- */
+const char* paris_hip_strerror(int status);
+/* library version "major.minor.patch" */
+const char* paris_hip_version(void);
+/* Times the most recent backproject launch on this ctx (HIP events recorded on the ctx stream around the
+ * kernel); synchronises the stream. Used by bench.py for roofline.achieved. */
+int paris_hip_last_backproject_ms(paris_hip_ctx* ctx, float* ms);
+/* Arms a ring of `capacity` HIP event pairs: every following backproject launch on this ctx is bracketed by
+ * events on the ctx stream. _collect synchronises the stream and returns the durations (ms) of the launches
+ * still in the ring, oldest first. Default capacity is 1 (paris_hip_last_backproject_ms). */
+int paris_hip_backproject_timing_arm(paris_hip_ctx* ctx, uint32_t capacity);
+int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* ms, uint32_t max_n, uint32_t* n_out);
+/* Selects the backprojection kernel variant: 0 = default (LDS-staged), 1 = reference-order gather kernel
+ * without LDS (slow, for cross-checking). */
+int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant);
+/* Tuning knobs of the LDS-staged kernel; 0 keeps the default. vx: voxels per lane along x (1, 2, 4; capped by
+ * the volume's alignment), unroll: z slices in flight per lane (1, 2, 4), tz: slices per tile, lds_bytes: LDS
+ * budget per workgroup for the staged detector box (1024..65536). Results do not depend on any of them. */
+int paris_hip_set_backproject_tuning(paris_hip_ctx* ctx, int vx, int unroll, int tz, int lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARIS_HIP_H_ */

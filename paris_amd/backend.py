@@ -1,0 +1,323 @@
+"""Host-side mirror of the PARIS backend surface for the MI355X HIP backend.
+
+The reference's backend is a C++ namespace with 14 free functions plus buffer types
+(src/generic/backend.h:54-88, src/openmp/backend.h:42-89, src/cuda/backend.h:50-103). This module exposes
+the same names, argument meaning and error behaviour over the C ABI of include/paris_hip.h, so the parity
+tests read like a PARIS driver loop (src/main.cpp:98-105). The C++ equivalent is paris_amd/host/.
+
+All numeric work happens in libparis_hip.so on the GPU; there is no CPU path here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (DetectorGeometry, ParisHipError, RegionOfInterest, SubvolumeGeometry, SubvolumeInfo,
+                   VolumeGeometry, check)
+
+__all__ = ["DetectorGeometry", "VolumeGeometry", "SubvolumeGeometry", "RegionOfInterest", "SubvolumeInfo",
+           "ParisHipError", "Projection", "Volume", "FilterBuffer", "Backend", "get_devices", "set_device",
+           "calculate_volume_geometry", "apply_roi", "filter_size", "load", "make_volume", "weight", "filter",
+           "backproject"]
+
+
+class Projection:
+    """paris::projection<Buffer, Metadata> (src/projection.h:31-46). `buf` is a numpy array (host) or a device
+    address (device); `pitch` is the row stride in bytes."""
+
+    def __init__(self, buf, dim_x, dim_y, idx=0, phi=0.0, pitch=None, on_device=False, owner=None):
+        self.buf = buf
+        self.dim_x = dim_x
+        self.dim_y = dim_y
+        self.idx = idx
+        self.phi = phi
+        self.pitch = pitch if pitch is not None else dim_x * 4
+        self.on_device = on_device
+        self._owner = owner  # Backend that must free buf, or an object that keeps it alive
+
+    @property
+    def ptr(self):
+        return self.buf if self.on_device else self.buf.ctypes.data
+
+
+class Volume:
+    """paris::volume<Buffer> (src/volume.h:31-45); x fastest, then y, then z."""
+
+    def __init__(self, buf, dim_x, dim_y, dim_z, off=0, on_device=False, owner=None):
+        self.buf = buf
+        self.dim_x = dim_x
+        self.dim_y = dim_y
+        self.dim_z = dim_z
+        self.off = off
+        self.on_device = on_device
+        self._owner = owner
+
+    @property
+    def ptr(self):
+        return self.buf if self.on_device else self.buf.ctypes.data
+
+
+class FilterBuffer:
+    """backend::filter_buffer_type: K = tau * |rFFT(r)|, size/2+1 floats on the device."""
+
+    def __init__(self, ptr, size, backend):
+        self.ptr = ptr
+        self.size = size
+        self._backend = backend
+
+
+class Backend:
+    """One device + stream: the state the reference keeps in thread_local statics after set_device
+    (src/main.cpp:87). synchronous=True reproduces the reference's blocking calls."""
+
+    def __init__(self, device=0, stream=None, synchronous=True):
+        self._L = _lib.load()
+        ctx = C.c_void_p()
+        flags = _lib.CTX_SYNCHRONOUS if synchronous else _lib.CTX_DEFAULT
+        check(self._L.paris_hip_ctx_create(device, C.c_void_p(stream) if stream else None, flags, C.byref(ctx)),
+              "paris_hip_ctx_create")
+        self._ctx = ctx
+        self.device = device
+        self._owned = set()
+
+    # ---- lifetime ------------------------------------------------------------------------------------
+    def close(self):
+        if self._ctx is not None:
+            for p in list(self._owned):
+                self._L.paris_hip_free(self._ctx, C.c_void_p(p))
+            self._owned.clear()
+            self._L.paris_hip_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self._L.paris_hip_ctx_synchronize(self._ctx), "paris_hip_ctx_synchronize")
+
+    @property
+    def stream(self):
+        return self._L.paris_hip_ctx_stream(self._ctx)
+
+    def free(self, obj):
+        ptr = obj.ptr if hasattr(obj, "ptr") else obj
+        if ptr in self._owned:
+            check(self._L.paris_hip_free(self._ctx, C.c_void_p(ptr)), "paris_hip_free")
+            self._owned.discard(ptr)
+
+    # ---- memory (src/openmp/memory.cpp:33-79, src/cuda/memory.cpp:33-102) -------------------------------
+    def make_projection_host(self, dim_x, dim_y):
+        return Projection(np.empty((dim_y, dim_x), np.float32), dim_x, dim_y)
+
+    def make_projection_device(self, dim_x, dim_y):
+        ptr, pitch = C.c_void_p(), C.c_size_t()
+        check(self._L.paris_hip_malloc_projection(self._ctx, dim_x, dim_y, C.byref(ptr), C.byref(pitch)),
+              "paris_hip_malloc_projection")
+        self._owned.add(ptr.value)
+        return Projection(ptr.value, dim_x, dim_y, pitch=pitch.value, on_device=True, owner=self)
+
+    def make_volume_host(self, dim_x, dim_y, dim_z):
+        return Volume(np.zeros((dim_z, dim_y, dim_x), np.float32), dim_x, dim_y, dim_z)
+
+    def make_volume_device(self, dim_x, dim_y, dim_z):
+        ptr = C.c_void_p()
+        check(self._L.paris_hip_malloc_volume(self._ctx, dim_x, dim_y, dim_z, C.byref(ptr)),
+              "paris_hip_malloc_volume")
+        self._owned.add(ptr.value)
+        return Volume(ptr.value, dim_x, dim_y, dim_z, on_device=True, owner=self)
+
+    def wrap_projection(self, ptr, pitch, dim_x, dim_y, idx=0, phi=0.0, owner=None):
+        """Adopts device memory allocated elsewhere (e.g. a torch tensor's data_ptr())."""
+        return Projection(ptr, dim_x, dim_y, idx, phi, pitch=pitch, on_device=True, owner=owner)
+
+    def wrap_volume(self, ptr, dim_x, dim_y, dim_z, off=0, owner=None):
+        return Volume(ptr, dim_x, dim_y, dim_z, off, on_device=True, owner=owner)
+
+    def copy_h2d(self, h, d):
+        """copy_h2d for projections (carries idx, phi: src/openmp/memory.cpp:60-62) and volumes (off: :73)."""
+        if isinstance(h, Projection):
+            assert h.buf.dtype == np.float32 and h.dim_x == d.dim_x and h.dim_y == d.dim_y
+            check(self._L.paris_hip_memcpy_projection_h2d(self._ctx, d.ptr, d.pitch, h.ptr, h.buf.strides[0],
+                                                          h.dim_x, h.dim_y), "paris_hip_memcpy_projection_h2d")
+            d.idx, d.phi = h.idx, h.phi
+        else:
+            assert h.buf.dtype == np.float32 and (h.dim_x, h.dim_y, h.dim_z) == (d.dim_x, d.dim_y, d.dim_z)
+            check(self._L.paris_hip_memcpy_volume_h2d(self._ctx, d.ptr, h.ptr, h.dim_x, h.dim_y, h.dim_z),
+                  "paris_hip_memcpy_volume_h2d")
+            d.off = h.off
+        self.synchronize()
+
+    def copy_d2h(self, d, h):
+        if isinstance(d, Projection):
+            assert h.buf.dtype == np.float32 and h.dim_x == d.dim_x and h.dim_y == d.dim_y
+            check(self._L.paris_hip_memcpy_projection_d2h(self._ctx, h.ptr, h.buf.strides[0], d.ptr, d.pitch,
+                                                          d.dim_x, d.dim_y), "paris_hip_memcpy_projection_d2h")
+            h.idx, h.phi = d.idx, d.phi
+        else:
+            assert h.buf.dtype == np.float32 and (h.dim_x, h.dim_y, h.dim_z) == (d.dim_x, d.dim_y, d.dim_z)
+            check(self._L.paris_hip_memcpy_volume_d2h(self._ctx, h.ptr, d.ptr, d.dim_x, d.dim_y, d.dim_z),
+                  "paris_hip_memcpy_volume_d2h")
+            h.off = d.off
+        self.synchronize()
+
+    def make_subvolume_information(self, vol_geo, det_geo, n_devices=0):
+        """src/cuda/subvolume_information.cpp:63-118"""
+        out = SubvolumeInfo()
+        check(self._L.paris_hip_make_subvolume_information(C.byref(vol_geo), C.byref(det_geo), n_devices,
+                                                           C.byref(out)), "paris_hip_make_subvolume_information")
+        return out
+
+    # ---- the three numeric stages --------------------------------------------------------------------------
+    def weight(self, p, h_min, v_min, d_sd, l_px_row, l_px_col):
+        """backend::weight (src/openmp/weighting.cpp:32-57)"""
+        check(self._L.paris_hip_weight(self._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, h_min, v_min, d_sd,
+                                       l_px_row, l_px_col), "paris_hip_weight")
+
+    def make_filter(self, size, tau):
+        """backend::make_filter (src/openmp/filtering.cpp:139-165)"""
+        ptr = C.c_void_p()
+        check(self._L.paris_hip_make_filter(self._ctx, size, tau, C.byref(ptr)), "paris_hip_make_filter")
+        self._owned.add(ptr.value)
+        return FilterBuffer(ptr.value, size, self)
+
+    def filter_to_host(self, k):
+        n = k.size // 2 + 1
+        out = np.empty((1, n), np.float32)
+        check(self._L.paris_hip_memcpy_projection_d2h(self._ctx, out.ctypes.data, n * 4, k.ptr, n * 4, n, 1),
+              "paris_hip_memcpy_projection_d2h")
+        self.synchronize()
+        return out[0]
+
+    def apply_filter(self, p, k, filter_size, n_col):
+        """backend::apply_filter (src/openmp/filtering.cpp:167-219)"""
+        check(self._L.paris_hip_apply_filter(self._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, k.ptr, filter_size,
+                                             n_col), "paris_hip_apply_filter")
+
+    def backproject(self, p, v, v_offset, det_geo, vol_geo, enable_roi, roi, sin, cos, delta_s, delta_t):
+        """backend::backproject (src/openmp/backprojection.cpp:156-199)"""
+        r = roi if roi is not None else RegionOfInterest()
+        check(self._L.paris_hip_backproject(self._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, v.ptr, v.dim_x, v.dim_y,
+                                            v.dim_z, v_offset, C.byref(det_geo), C.byref(vol_geo),
+                                            int(bool(enable_roi)), C.byref(r), sin, cos, delta_s, delta_t),
+              "paris_hip_backproject")
+
+    def backproject_batch(self, p_ptr, p_pitch, p_stride, n_proj, p_dim_x, p_dim_y, v, v_offset, det_geo, vol_geo,
+                          enable_roi, roi, sins, coss, delta_s, delta_t):
+        r = roi if roi is not None else RegionOfInterest()
+        s = (C.c_float * n_proj)(*sins)
+        c = (C.c_float * n_proj)(*coss)
+        check(self._L.paris_hip_backproject_batch(self._ctx, p_ptr, p_pitch, p_stride, n_proj, p_dim_x, p_dim_y,
+                                                  v.ptr, v.dim_x, v.dim_y, v.dim_z, v_offset, C.byref(det_geo),
+                                                  C.byref(vol_geo), int(bool(enable_roi)), C.byref(r), s, c,
+                                                  delta_s, delta_t), "paris_hip_backproject_batch")
+
+    # ---- diagnostics ------------------------------------------------------------------------------------------
+    def last_backproject_ms(self):
+        ms = C.c_float()
+        check(self._L.paris_hip_last_backproject_ms(self._ctx, C.byref(ms)), "paris_hip_last_backproject_ms")
+        return ms.value
+
+    def backproject_timing_arm(self, capacity):
+        check(self._L.paris_hip_backproject_timing_arm(self._ctx, capacity), "paris_hip_backproject_timing_arm")
+
+    def backproject_timing_collect(self, max_n=65536):
+        ms = (C.c_float * max_n)()
+        n = C.c_uint32()
+        check(self._L.paris_hip_backproject_timing_collect(self._ctx, ms, max_n, C.byref(n)),
+              "paris_hip_backproject_timing_collect")
+        return list(ms[:n.value])
+
+    def set_backproject_variant(self, variant):
+        check(self._L.paris_hip_set_backproject_variant(self._ctx, variant), "paris_hip_set_backproject_variant")
+
+    def set_backproject_tuning(self, vx=0, unroll=0, tz=0, lds_bytes=0):
+        check(self._L.paris_hip_set_backproject_tuning(self._ctx, vx, unroll, tz, lds_bytes),
+              "paris_hip_set_backproject_tuning")
+
+
+# ---- device management (src/cuda/device.cpp:31-47, src/openmp/backend.h:87-89) --------------------------------
+
+def get_devices():
+    n = C.c_int()
+    check(_lib.load().paris_hip_device_count(C.byref(n)), "paris_hip_device_count")
+    return list(range(n.value))
+
+
+def set_device(device, stream=None, synchronous=True):
+    """Binds the calling thread's work to `device`; returns the Backend that carries the per-device state."""
+    return Backend(device, stream, synchronous)
+
+
+# ---- geometry (src/geometry.cpp) -----------------------------------------------------------------------------
+
+def calculate_volume_geometry(det_geo):
+    out = VolumeGeometry()
+    check(_lib.load().paris_hip_calculate_volume_geometry(C.byref(det_geo), C.byref(out)),
+          "paris_hip_calculate_volume_geometry")
+    return out
+
+
+def apply_roi(vol_geo, x1, x2, y1, y2, z1, z2):
+    out = VolumeGeometry()
+    roi = RegionOfInterest(x1, x2, y1, y2, z1, z2)
+    check(_lib.load().paris_hip_apply_roi(C.byref(vol_geo), C.byref(roi), C.byref(out)), "paris_hip_apply_roi")
+    return out
+
+
+def filter_size(n_row):
+    return int(_lib.load().paris_hip_filter_size(n_row))
+
+
+# ---- stage wrappers (src/loader.cpp, make_volume.cpp, weighting.cpp, filtering.cpp, backprojection.cpp) --------
+
+def load(backend, p):
+    """paris::load (src/loader.cpp:28-33)"""
+    d_p = backend.make_projection_device(p.dim_x, p.dim_y)
+    backend.copy_h2d(p, d_p)
+    return d_p
+
+
+def make_volume(backend, subvol_geo, last):
+    """paris::make_volume (src/make_volume.cpp:30-37)"""
+    dim_z = subvol_geo.dim_z
+    if last:
+        dim_z += subvol_geo.remainder
+    return backend.make_volume_device(subvol_geo.dim_x, subvol_geo.dim_y, dim_z)
+
+
+def weight(backend, p, det_geo):
+    """paris::weight (src/weighting.cpp:32-45)"""
+    check(backend._L.paris_hip_stage_weight(backend._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, C.byref(det_geo)),
+          "paris_hip_stage_weight")
+
+
+def filter(backend, p, det_geo):  # noqa: A001 - the reference's name
+    """paris::filter (src/filtering.cpp:32-45)"""
+    check(backend._L.paris_hip_stage_filter(backend._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, C.byref(det_geo)),
+          "paris_hip_stage_filter")
+
+
+def backproject(backend, p, v, v_offset, det_geo, vol_geo, enable_angles, enable_roi, roi):
+    """paris::backproject (src/backprojection.cpp:37-69)"""
+    r = roi if roi is not None else RegionOfInterest()
+    check(backend._L.paris_hip_stage_backproject(backend._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, p.idx, p.phi,
+                                                 v.ptr, v.dim_x, v.dim_y, v.dim_z, v_offset, C.byref(det_geo),
+                                                 C.byref(vol_geo), int(bool(enable_angles)),
+                                                 int(bool(enable_roi)), C.byref(r)),
+          "paris_hip_stage_backproject")
+
+
+def stage_angle(det_geo, idx, enable_angles=False, phi=0.0):
+    s, c = C.c_float(), C.c_float()
+    check(_lib.load().paris_hip_stage_angle(C.byref(det_geo), idx, int(bool(enable_angles)), phi, C.byref(s),
+                                            C.byref(c)), "paris_hip_stage_angle")
+    return s.value, c.value

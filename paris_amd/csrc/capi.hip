@@ -1,0 +1,355 @@
+// Context, memory and device management entry points of libparis_hip.so (include/paris_hip.h).
+//
+// Replaces the reference's per-backend device/memory/stream files: src/cuda/device.cpp, src/cuda/stream.cpp,
+// src/cuda/memory.cpp, src/cuda/subvolume_information.cpp (and their trivial OpenMP counterparts
+// src/openmp/memory.cpp, src/openmp/subvolume_information.cpp). All implicit thread_local state of the
+// reference lives in paris_hip_ctx.
+#include "paris_hip_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+extern "C" int paris_hip_device_count(int* count)
+{
+    if(count == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    int n = 0;
+    const hipError_t err = hipGetDeviceCount(&n);
+    if(err == hipErrorNoDevice)
+    {
+        *count = 0;
+        return PARIS_HIP_SUCCESS;
+    }
+    PARIS_HIP_TRY(err);
+    *count = n;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_ctx_create(int device, void* stream, unsigned flags, paris_hip_ctx** out)
+{
+    if(out == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if(int rc = paris_hip_device_count(&n))
+        return rc;
+    if(n == 0)
+        return PARIS_HIP_ERROR_NO_DEVICE;
+    if(device < 0 || device >= n)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    PARIS_HIP_TRY(hipSetDevice(device)); // set_device: src/cuda/device.cpp:40-47
+
+    paris_hip_ctx* ctx = new(std::nothrow) paris_hip_ctx;
+    if(ctx == nullptr)
+        return static_cast<int>(hipErrorOutOfMemory);
+    ctx->device = device;
+    ctx->flags = flags;
+    if(stream != nullptr)
+    {
+        ctx->stream = static_cast<hipStream_t>(stream);
+        ctx->owns_stream = false;
+    }
+    else
+    {
+        const hipError_t err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if(err != hipSuccess)
+        {
+            delete ctx;
+            return static_cast<int>(err);
+        }
+        ctx->owns_stream = true;
+    }
+    if(int rc = paris_hip_backproject_timing_arm(ctx, 1))
+    {
+        paris_hip_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return PARIS_HIP_SUCCESS;
+}
+
+static void destroy_events(paris_hip_ctx* ctx)
+{
+    for(hipEvent_t e : ctx->bp_start)
+        (void)hipEventDestroy(e);
+    for(hipEvent_t e : ctx->bp_stop)
+        (void)hipEventDestroy(e);
+    ctx->bp_start.clear();
+    ctx->bp_stop.clear();
+}
+
+extern "C" int paris_hip_backproject_timing_arm(paris_hip_ctx* ctx, uint32_t capacity)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(capacity == 0 || capacity > 65536u)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if(ctx->bp_start.size() != capacity)
+    {
+        destroy_events(ctx);
+        for(uint32_t i = 0; i < capacity; ++i)
+        {
+            hipEvent_t a = nullptr, b = nullptr;
+            PARIS_HIP_TRY(hipEventCreate(&a));
+            ctx->bp_start.push_back(a);
+            PARIS_HIP_TRY(hipEventCreate(&b));
+            ctx->bp_stop.push_back(b);
+        }
+    }
+    ctx->bp_launches = 0;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* ms, uint32_t max_n, uint32_t* n_out)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(ms == nullptr || n_out == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint64_t cap = ctx->bp_start.size();
+    const uint64_t have = ctx->bp_launches < cap ? ctx->bp_launches : cap;
+    const uint64_t first = ctx->bp_launches - have; // oldest launch still in the ring
+    uint32_t n = 0;
+    for(uint64_t i = first; i < ctx->bp_launches && n < max_n; ++i, ++n)
+        PARIS_HIP_TRY(hipEventElapsedTime(&ms[n], ctx->bp_start[i % cap], ctx->bp_stop[i % cap]));
+    *n_out = n;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
+{
+    if(ctx == nullptr)
+        return PARIS_HIP_SUCCESS;
+    (void)hipSetDevice(ctx->device);
+    if(ctx->stream != nullptr)
+        (void)hipStreamSynchronize(ctx->stream);
+    for(auto& kv : ctx->plans)
+        (void)hipFree(kv.second.d_twiddle);
+    if(ctx->d_sincos != nullptr)
+        (void)hipFree(ctx->d_sincos);
+    if(ctx->stage_k != nullptr)
+        (void)hipFree(ctx->stage_k);
+    for(hipEvent_t e : ctx->bp_start)
+        (void)hipEventDestroy(e);
+    for(hipEvent_t e : ctx->bp_stop)
+        (void)hipEventDestroy(e);
+    if(ctx->owns_stream && ctx->stream != nullptr)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_ctx_synchronize(paris_hip_ctx* ctx)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" void* paris_hip_ctx_stream(paris_hip_ctx* ctx)
+{
+    return ctx ? static_cast<void*>(ctx->stream) : nullptr;
+}
+
+// ---- memory ------------------------------------------------------------------------------------------
+
+extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, float** d_ptr,
+                                           size_t* pitch)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(d_ptr == nullptr || pitch == nullptr || dim_x == 0 || dim_y == 0)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    // rows padded to 256 B: every row starts on a cache-line pair and float4 staging stays aligned
+    const size_t row = (static_cast<size_t>(dim_x) * sizeof(float) + 255u) & ~static_cast<size_t>(255u);
+    void* p = nullptr;
+    PARIS_HIP_TRY(hipMalloc(&p, row * dim_y));
+    *d_ptr = static_cast<float*>(p);
+    *pitch = row;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_memset_volume(paris_hip_ctx* ctx, float* d_ptr, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(d_ptr == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    const size_t bytes = static_cast<size_t>(dim_x) * dim_y * dim_z * sizeof(float);
+    PARIS_HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, ctx->stream));
+    return paris_hip_finish(ctx);
+}
+
+extern "C" int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, float** d_ptr)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(d_ptr == nullptr || dim_x == 0 || dim_y == 0 || dim_z == 0)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    const size_t bytes = static_cast<size_t>(dim_x) * dim_y * dim_z * sizeof(float);
+    void* p = nullptr;
+    PARIS_HIP_TRY(hipMalloc(&p, bytes));
+    // make_volume_* zero-fills: src/openmp/memory.cpp:46-47, src/cuda/memory.cpp:55-56
+    const hipError_t err = hipMemsetAsync(p, 0, bytes, ctx->stream);
+    if(err != hipSuccess)
+    {
+        (void)hipFree(p);
+        return static_cast<int>(err);
+    }
+    *d_ptr = static_cast<float*>(p);
+    return paris_hip_finish(ctx);
+}
+
+extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(d_ptr == nullptr)
+        return PARIS_HIP_SUCCESS;
+    PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PARIS_HIP_TRY(hipFree(d_ptr));
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_malloc_host(paris_hip_ctx* ctx, size_t bytes, void** h_ptr)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(h_ptr == nullptr || bytes == 0)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    PARIS_HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_free_host(paris_hip_ctx* ctx, void* h_ptr)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(h_ptr == nullptr)
+        return PARIS_HIP_SUCCESS;
+    PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PARIS_HIP_TRY(hipHostFree(h_ptr));
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_memcpy_projection_h2d(paris_hip_ctx* ctx, float* d_dst, size_t d_pitch, const float* h_src,
+                                               size_t h_pitch, uint32_t dim_x, uint32_t dim_y)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(d_dst == nullptr || h_src == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
+                                   hipMemcpyHostToDevice, ctx->stream));
+    return paris_hip_finish(ctx);
+}
+
+extern "C" int paris_hip_memcpy_projection_d2h(paris_hip_ctx* ctx, float* h_dst, size_t h_pitch, const float* d_src,
+                                               size_t d_pitch, uint32_t dim_x, uint32_t dim_y)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(h_dst == nullptr || d_src == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    PARIS_HIP_TRY(hipMemcpy2DAsync(h_dst, h_pitch, d_src, d_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    return paris_hip_finish(ctx);
+}
+
+extern "C" int paris_hip_memcpy_volume_h2d(paris_hip_ctx* ctx, float* d_dst, const float* h_src, uint32_t dim_x,
+                                           uint32_t dim_y, uint32_t dim_z)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(d_dst == nullptr || h_src == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    const size_t bytes = static_cast<size_t>(dim_x) * dim_y * dim_z * sizeof(float);
+    PARIS_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return paris_hip_finish(ctx);
+}
+
+extern "C" int paris_hip_memcpy_volume_d2h(paris_hip_ctx* ctx, float* h_dst, const float* d_src, uint32_t dim_x,
+                                           uint32_t dim_y, uint32_t dim_z)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(h_dst == nullptr || d_src == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    const size_t bytes = static_cast<size_t>(dim_x) * dim_y * dim_z * sizeof(float);
+    PARIS_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return paris_hip_finish(ctx);
+}
+
+// ---- subvolume split ---------------------------------------------------------------------------------
+
+// src/cuda/subvolume_information.cpp:63-118: start with one slab per device and double the slab count until
+// (volume + 10 projections) / devices fits the free memory of every device. 64-bit sizes; the
+// reference's trial allocation is replaced by the free-memory test alone with a 5 % safety margin.
+extern "C" int paris_hip_make_subvolume_information(const paris_volume_geometry* vol_geo,
+                                                    const paris_detector_geometry* det_geo, int n_devices,
+                                                    paris_subvolume_info* out)
+{
+    if(vol_geo == nullptr || det_geo == nullptr || out == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    int devices = 0;
+    if(int rc = paris_hip_device_count(&devices))
+        return rc;
+    if(devices == 0)
+        return PARIS_HIP_ERROR_NO_DEVICE;
+    if(n_devices > 0)
+        devices = std::min(devices, n_devices);
+
+    const size_t vol = static_cast<size_t>(vol_geo->dim_x) * vol_geo->dim_y * vol_geo->dim_z * sizeof(float); // :53
+    const size_t proj = static_cast<size_t>(det_geo->n_row) * det_geo->n_col * sizeof(float);                // :54
+    size_t mem_needed = (vol + 10u * proj) / static_cast<size_t>(devices);                                     // :73-77
+    uint32_t vols_needed = static_cast<uint32_t>(devices);                                                     // :79
+
+    int current = 0;
+    (void)hipGetDevice(&current);
+    for(int d = 0; d < devices; ++d)
+    {
+        PARIS_HIP_TRY(hipSetDevice(d));
+        size_t mem_free = 0, mem_total = 0;
+        PARIS_HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
+        mem_free -= mem_free / 20u;
+        size_t mem_dev = mem_needed;
+        while(mem_dev >= mem_free && vols_needed < vol_geo->dim_z) // :91-95
+        {
+            mem_dev /= 2;
+            vols_needed *= 2;
+        }
+    }
+    (void)hipSetDevice(current);
+    if(vols_needed > vol_geo->dim_z)
+        vols_needed = vol_geo->dim_z ? vol_geo->dim_z : 1u;
+
+    out->geo.dim_x = vol_geo->dim_x; // :112-116
+    out->geo.dim_y = vol_geo->dim_y;
+    out->geo.dim_z = vol_geo->dim_z / vols_needed;
+    out->geo.remainder = vol_geo->dim_z % vols_needed;
+    out->num = static_cast<int>(vols_needed);
+    return PARIS_HIP_SUCCESS;
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------------------
+
+extern "C" const char* paris_hip_strerror(int status)
+{
+    switch(status)
+    {
+        case PARIS_HIP_SUCCESS: return "success";
+        case PARIS_HIP_ERROR_INVALID_ARGUMENT: return "paris_hip: invalid argument";
+        case PARIS_HIP_ERROR_NO_DEVICE: return "paris_hip: no HIP device";
+        case PARIS_HIP_ERROR_UNSUPPORTED: return "paris_hip: unsupported size";
+        default: return hipGetErrorString(static_cast<hipError_t>(status));
+    }
+}
+
+extern "C" const char* paris_hip_version(void)
+{
+    return "0.1.0";
+}

@@ -1,0 +1,74 @@
+// Internal declarations shared by the translation units of libparis_hip.so (gfx950 only).
+#ifndef PARIS_HIP_INTERNAL_H_
+#define PARIS_HIP_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <vector>
+
+#include "paris_hip.h"
+
+// Every fp32 operation of the numeric path must round once, in the reference's order (DESIGN.md,
+// "Numerics"): no FMA contraction anywhere in this library. The Makefile passes -ffp-contract=off as well.
+#pragma clang fp contract(off)
+
+#define PARIS_HIP_TRY(expr)                                   \
+    do                                                        \
+    {                                                         \
+        hipError_t paris_hip_err__ = (expr);                  \
+        if(paris_hip_err__ != hipSuccess)                     \
+            return static_cast<int>(paris_hip_err__);         \
+    } while(0)
+
+struct paris_hip_fft_plan
+{
+    float2* d_twiddle = nullptr; // exp(-2 pi i k / n), k < n/2
+};
+
+struct paris_hip_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    unsigned flags = 0;
+    // ring of HIP event pairs recorded on the ctx stream around backprojection launches (bench.py's
+    // roofline figure); capacity 1 by default, i.e. "the last launch"
+    std::vector<hipEvent_t> bp_start, bp_stop;
+    uint64_t bp_launches = 0; // launches recorded since the ring was (re)armed
+    int bp_variant = 0;
+    int bp_vx = 0, bp_unroll = 0; // 0 = automatic
+    uint32_t bp_tz = 0, bp_lds_bytes = 0;
+    bool filter_lds_attr_set = false;
+    std::map<uint32_t, paris_hip_fft_plan> plans; // keyed by FFT length
+    // K cached by paris_hip_stage_filter (reference: thread_local static in src/filtering.cpp:42)
+    float* stage_k = nullptr;
+    uint32_t stage_k_size = 0;
+    float stage_k_tau = 0.f;
+    // device copies of the per-projection sin/cos for the batched launch
+    float* d_sincos = nullptr;
+    uint32_t d_sincos_cap = 0;
+};
+
+// finishes a call: propagates launch errors, honours PARIS_HIP_CTX_SYNCHRONOUS
+inline int paris_hip_finish(paris_hip_ctx* ctx)
+{
+    PARIS_HIP_TRY(hipGetLastError());
+    if(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS)
+        PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PARIS_HIP_SUCCESS;
+}
+
+inline int paris_hip_bind(paris_hip_ctx* ctx)
+{
+    if(ctx == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    PARIS_HIP_TRY(hipSetDevice(ctx->device));
+    return PARIS_HIP_SUCCESS;
+}
+
+int paris_hip_get_plan(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_plan** out);
+
+#endif

@@ -1,0 +1,46 @@
+// Cosine pre-weighting for gfx950.
+//
+// Replaces paris::openmp::weight (src/openmp/weighting.cpp:32-57) / paris::cuda::weight
+// (src/cuda/weighting.cu:35-73) behind paris_hip_weight. The CUDA backend uses rsqrtf; this kernel uses
+// the OpenMP backend's IEEE sqrt + divide so the result is bit-identical to the parity target.
+// HBM-bound: 8 B per pixel (one read, one write).
+#include "paris_hip_internal.h"
+
+namespace
+{
+    __global__ void __launch_bounds__(256)
+        weight_kernel(float* p, uint32_t pitch_f, uint32_t dim_x, uint32_t dim_y, float h_min, float v_min,
+                      float d_sd, float l_px_row, float l_px_col)
+    {
+        const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+        if(s >= dim_x)
+            return;
+        const float s_f = static_cast<float>(s);
+        const float h_s = (l_px_row / 2) + s_f * l_px_row + h_min; // src/openmp/weighting.cpp:48
+        const float hh = h_s * h_s;
+        const float dd = d_sd * d_sd;
+        for(uint32_t t = blockIdx.y; t < dim_y; t += gridDim.y)
+        {
+            const float t_f = static_cast<float>(t);
+            const float v_t = (l_px_col / 2) + t_f * l_px_col + v_min; // :49
+            const float w_st = d_sd / sqrtf(dd + hh + v_t * v_t);      // :52
+            float* px = p + static_cast<size_t>(t) * pitch_f + s;
+            *px *= w_st; // :54
+        }
+    }
+}
+
+extern "C" int paris_hip_weight(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                                float h_min, float v_min, float d_sd, float l_px_row, float l_px_col)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(d_p == nullptr || pitch < static_cast<size_t>(dim_x) * sizeof(float) || pitch % sizeof(float) != 0)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(dim_x == 0 || dim_y == 0)
+        return paris_hip_finish(ctx);
+    const dim3 grid((dim_x + 255u) / 256u, dim_y < 65535u ? dim_y : 65535u);
+    hipLaunchKernelGGL(weight_kernel, grid, dim3(256), 0, ctx->stream, d_p, static_cast<uint32_t>(pitch / sizeof(float)),
+                       dim_x, dim_y, h_min, v_min, d_sd, l_px_row, l_px_col);
+    return paris_hip_finish(ctx);
+}

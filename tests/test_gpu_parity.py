@@ -1,0 +1,392 @@
+"""Parity of the HIP path (through the C ABI, include/paris_hip.h) against the CPU oracle and the golden fixtures.
+
+Bars (DESIGN.md "Numerics"):
+  weighting, backprojection : bit-exact (same fp32 operations in the same order, IEEE divide/sqrt, no FMA)
+  make_filter / apply_filter: the FFT is a third-party library in the reference (FFTW3f), so parity is to FFT
+                              rounding: max-abs error <= 1e-5 * max|x| and relative L2 error <= 1e-5
+"""
+import os
+
+import numpy as np
+import pytest
+
+from paris_amd import _lib
+from paris_amd import backend as B
+
+pytestmark = pytest.mark.gpu
+
+FILTER_TOL = 1e-5
+
+KAT = (64, 48, 0.2, 0.25, 1.5, -0.75, 100, 200, 45)
+
+
+@pytest.fixture(scope="module")
+def be():
+    b = B.set_device(B.get_devices()[0])
+    yield b
+    b.close()
+
+
+@pytest.fixture(scope="module")
+def kat_golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "kat.npz"))
+
+
+def to_device(be, host_array, idx=0, phi=0.0):
+    h = B.Projection(np.ascontiguousarray(host_array, np.float32), host_array.shape[1], host_array.shape[0], idx, phi)
+    return B.load(be, h)
+
+
+def to_host(be, d_p):
+    h = be.make_projection_host(d_p.dim_x, d_p.dim_y)
+    be.copy_d2h(d_p, h)
+    return h.buf
+
+
+def volume_to_host(be, d_v):
+    h = be.make_volume_host(d_v.dim_x, d_v.dim_y, d_v.dim_z)
+    be.copy_d2h(d_v, h)
+    return h.buf
+
+
+def rel_l2(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    return np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-300))
+
+
+# ---- weighting ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("g", [KAT, (512, 384, 0.2, 0.2, 0, 0, 500, 500, 1.0),
+                               (333, 217, 0.127, 0.254, -3.25, 2.5, 321.5, 123.25, 0.7)])
+def test_weight_bit_exact(be, oracle, g):
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    p = oracle.lcg_projection(det.n_row, det.n_col, 3)
+    d_p = to_device(be, p)
+    B.weight(be, d_p, det)  # paris::weight wrapper
+    got = to_host(be, d_p)
+    want = oracle.weight(p.copy(), odet)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    be.free(d_p)
+
+
+def test_weight_golden(be, oracle, kat_golden):
+    det = B.DetectorGeometry(*KAT)
+    d_p = to_device(be, oracle.lcg_projection(64, 48, 0))
+    B.weight(be, d_p, det)
+    assert np.array_equal(to_host(be, d_p), kat_golden["weighted_p0"])
+    be.free(d_p)
+
+
+def test_weight_backend_level_call(be, oracle):
+    """backend::weight with explicit constants (src/openmp/weighting.cpp:32) == wrapper"""
+    odet = oracle.DetectorGeometry(*KAT)
+    h_min, v_min, d_sd = oracle.weight_constants(odet)
+    p = oracle.lcg_projection(64, 48, 1)
+    d_p = to_device(be, p)
+    be.weight(d_p, h_min, v_min, d_sd, odet.l_px_row, odet.l_px_col)
+    assert np.array_equal(to_host(be, d_p), oracle.weight(p.copy(), odet))
+    be.free(d_p)
+
+
+# ---- filtering ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,tau", [(8, 0.5), (128, 0.2), (1024, 0.2), (2048, 0.127), (4096, 0.2), (16384, 0.1)])
+def test_make_filter(be, oracle, n, tau):
+    k = be.make_filter(n, tau)
+    got = be.filter_to_host(k)
+    want = oracle.make_filter(n, tau)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= FILTER_TOL * np.abs(want).max()
+    r = oracle.make_filter_real(n, tau).astype(np.float64)
+    exact = tau * np.abs(np.fft.rfft(r))
+    assert np.max(np.abs(got - exact)) <= FILTER_TOL * exact.max()
+    be.free(k)
+
+
+def test_make_filter_golden(be, kat_golden):
+    for n in (128, 1024, 2048, 4096):
+        k = be.make_filter(n, 0.2)
+        want = kat_golden["k_%d" % n]
+        assert np.max(np.abs(be.filter_to_host(k) - want)) <= FILTER_TOL * want.max()
+        be.free(k)
+
+
+@pytest.mark.parametrize("n_row,n_col", [(64, 48), (512, 37), (1000, 8), (5, 3), (2048, 6), (4097, 2)])
+def test_apply_filter(be, oracle, n_row, n_col):
+    fs = oracle.filter_size(n_row)
+    assert B.filter_size(n_row) == fs
+    tau = 0.2
+    p = oracle.lcg_projection(n_row, n_col, 11) - np.float32(0.25)
+    want = oracle.apply_filter(p.copy(), oracle.make_filter(fs, tau), fs)
+    d_p = to_device(be, p)
+    k = be.make_filter(fs, tau)
+    be.apply_filter(d_p, k, fs, n_col)
+    got = to_host(be, d_p)
+    assert np.max(np.abs(got - want)) <= FILTER_TOL * np.abs(want).max()
+    assert rel_l2(got, want) <= FILTER_TOL
+    # float64 reference of the same operation
+    kk = tau * np.abs(np.fft.rfft(oracle.make_filter_real(fs, tau).astype(np.float64)))
+    exact = np.fft.irfft(np.fft.rfft(p.astype(np.float64), fs, axis=1) * kk[None, :], fs, axis=1)[:, :n_row]
+    assert rel_l2(got, exact) <= FILTER_TOL
+    be.free(d_p)
+    be.free(k)
+
+
+def test_filter_wrapper_and_golden(be, oracle, kat_golden):
+    det = B.DetectorGeometry(*KAT)
+    for i in (0, 7):
+        d_p = to_device(be, oracle.lcg_projection(64, 48, i))
+        B.weight(be, d_p, det)
+        B.filter(be, d_p, det)  # paris::filter wrapper (K cached in the ctx)
+        got = to_host(be, d_p)
+        want = kat_golden["filtered"][i]
+        assert np.max(np.abs(got - want)) <= FILTER_TOL * np.abs(want).max()
+        be.free(d_p)
+
+
+def test_apply_filter_rejects_bad_arguments(be, oracle):
+    d_p = to_device(be, oracle.lcg_projection(64, 4, 0))
+    k = be.make_filter(64, 0.2)
+    L = _lib.load()
+    assert L.paris_hip_apply_filter(be._ctx, d_p.ptr, d_p.pitch, 64, 4, k.ptr, 32, 4) == _lib.ERROR_INVALID_ARGUMENT
+    assert L.paris_hip_apply_filter(be._ctx, d_p.ptr, d_p.pitch, 64, 4, k.ptr, 100, 4) == _lib.ERROR_INVALID_ARGUMENT
+    assert L.paris_hip_apply_filter(be._ctx, d_p.ptr, d_p.pitch, 64, 4, k.ptr, 64, 5) == _lib.ERROR_INVALID_ARGUMENT
+    import ctypes as C
+    out = C.c_void_p()
+    assert L.paris_hip_make_filter(be._ctx, 100, 0.2, C.byref(out)) == _lib.ERROR_INVALID_ARGUMENT
+    assert L.paris_hip_make_filter(be._ctx, 32768, 0.2, C.byref(out)) == _lib.ERROR_INVALID_ARGUMENT
+    be.free(d_p)
+    be.free(k)
+
+
+# ---- backprojection --------------------------------------------------------------------------------------------
+
+def hip_backproject_all(be, projections, det, vol_geo, v_dims, v_offset=0, roi=None, enable_angles=False):
+    """The reference's hot loop (src/main.cpp:98-105) from already filtered projections."""
+    dz, dy, dx = v_dims
+    d_v = be.make_volume_device(dx, dy, dz)
+    for i, p in enumerate(projections):
+        d_p = to_device(be, p, idx=i)
+        B.backproject(be, d_p, d_v, v_offset, det, vol_geo, enable_angles, roi is not None, roi)
+        be.free(d_p)
+    out = volume_to_host(be, d_v)
+    be.free(d_v)
+    return out
+
+
+def oracle_backproject_all(oracle, projections, odet, ovg, v_dims, v_offset=0, roi=None):
+    vol = np.zeros(v_dims, np.float32)
+    for i, p in enumerate(projections):
+        s, c, ds, dt = oracle.backproject_constants(odet, i)
+        oracle.backproject(vol, p, v_offset, odet, ovg, s, c, ds, dt, roi)
+    return vol
+
+
+def assert_bit_equal(got, want):
+    same = got.view(np.uint32) == want.view(np.uint32)
+    if not same.all():
+        bad = np.argwhere(~same)
+        z, y, x = bad[0]
+        raise AssertionError("%d of %d voxels differ; first at (x=%d,y=%d,z=%d): got %r want %r" % (
+            len(bad), got.size, x, y, z, got[z, y, x], want[z, y, x]))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_backproject_kat_full_bit_exact(be, oracle, kat_golden, variant):
+    det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
+    vg = B.calculate_volume_geometry(det)
+    be.set_backproject_variant(variant)
+    try:
+        got = hip_backproject_all(be, kat_golden["filtered"], det, vg, (61, 67, 67))
+    finally:
+        be.set_backproject_variant(0)
+    assert_bit_equal(got, kat_golden["volume"])
+    ovg = oracle.calculate_volume_geometry(odet)
+    assert_bit_equal(got, oracle_backproject_all(oracle, kat_golden["filtered"], odet, ovg, (61, 67, 67)))
+
+
+def test_backproject_kat_slab_and_roi_bit_exact(be, oracle, kat_golden):
+    det = B.DetectorGeometry(*KAT)
+    vg = B.calculate_volume_geometry(det)
+    full = kat_golden["volume"]
+    slab = hip_backproject_all(be, kat_golden["filtered"], det, vg, (31, 67, 67), v_offset=30)
+    assert_bit_equal(slab, full[30:61])
+    roi = B.RegionOfInterest(8, 40, 4, 36, 10, 30)
+    rg = B.apply_roi(vg, 8, 40, 4, 36, 10, 30)
+    assert (rg.dim_x, rg.dim_y, rg.dim_z) == (32, 32, 20)
+    rv = hip_backproject_all(be, kat_golden["filtered"], det, vg, (20, 32, 32), roi=roi)
+    assert_bit_equal(rv, full[10:30, 4:36, 8:40])
+    # ROI and slab offset together (src/openmp/backprojection.cpp:105-113): second half of the ROI's slices
+    rs = hip_backproject_all(be, kat_golden["filtered"], det, vg, (10, 32, 32), v_offset=10, roi=roi)
+    assert_bit_equal(rs, full[20:30, 4:36, 8:40])
+
+
+@pytest.mark.parametrize("tuning", [dict(vx=1, unroll=1), dict(vx=1, unroll=4), dict(vx=2, unroll=2),
+                                    dict(vx=2, unroll=4), dict(vx=4, unroll=1), dict(vx=4, unroll=2),
+                                    dict(vx=4, unroll=4), dict(vx=4, unroll=2, tz=8), dict(vx=4, unroll=2, tz=50),
+                                    dict(vx=4, unroll=2, lds_bytes=1024), dict(vx=2, unroll=4, lds_bytes=4096),
+                                    dict(vx=1, unroll=2, lds_bytes=65536, tz=64)])
+def test_backproject_every_kernel_shape_bit_exact(be, oracle, tuning):
+    """Noise projections into a 72 x 40 x 45 volume whose dims exercise partial tiles; every lane width, unroll,
+    tile depth and LDS budget (down to one that forces the global-memory tap path) gives the oracle's bits."""
+    g = (96, 80, 0.2, 0.25, -2.5, 1.25, 150, 250, 40.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(72, 40, 45, nat.l_vx_x * 1.3, nat.l_vx_x * 2.0, nat.l_vx_x * 1.7)
+    ovg = oracle.VolumeGeometry(72, 40, 45, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    projs = [oracle.lcg_projection(96, 80, i) - np.float32(0.5) for i in range(9)]
+    want = oracle_backproject_all(oracle, projs, odet, ovg, (45, 40, 72))
+    be.set_backproject_tuning(**tuning)
+    try:
+        got = hip_backproject_all(be, projs, det, vg, (45, 40, 72))
+    finally:
+        be.set_backproject_tuning()
+    assert_bit_equal(got, want)
+
+
+def test_backproject_cube64_golden(be, oracle, golden_dir):
+    gold = np.load(os.path.join(golden_dir, "cube64.npz"))
+    g = (64, 64, 0.2, 0.2, 0, 0, 100, 200, 45.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    vg = B.calculate_volume_geometry(det)
+    filtered = []
+    oracle.reconstruct(odet, oracle.calculate_volume_geometry(odet), 8, filtered_out=filtered)
+    got = hip_backproject_all(be, filtered, det, vg, (64, 64, 64))
+    assert_bit_equal(got[31:34], gold["slices"])
+    assert got.sum(dtype=np.float64) == float(gold["sum"])
+
+
+def test_backproject_detector_edges_and_empty_views(be, oracle):
+    """Volume much larger than the cone: most rays miss the detector (strict-inside rule); a detector
+    offset pushes the valid region to one side. Negative d_so gives whatever the oracle gives."""
+    for g, dims, scale in (((40, 30, 0.4, 0.4, 6.0, -4.0, 120, 80, 33.0), (50, 52, 56), 3.0),
+                           ((40, 30, 0.4, 0.4, 0.0, 0.0, -120, 80, 33.0), (20, 24, 28), 1.0)):
+        det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+        nat = B.calculate_volume_geometry(det)
+        dz, dy, dx = dims
+        vg = B.VolumeGeometry(dx, dy, dz, nat.l_vx_x * scale, nat.l_vx_x * scale, nat.l_vx_x * scale)
+        ovg = oracle.VolumeGeometry(dx, dy, dz, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+        projs = [oracle.lcg_projection(40, 30, i) for i in range(11)]
+        want = oracle_backproject_all(oracle, projs, odet, ovg, dims)
+        got = hip_backproject_all(be, projs, det, vg, dims)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) or \
+            (np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)]))
+
+
+def test_backproject_with_angle_file_values(be, oracle):
+    """enable_angles: phi comes from projection::phi instead of idx * delta_phi (src/backprojection.cpp:52-57)."""
+    det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
+    vg, ovg = B.calculate_volume_geometry(det), oracle.calculate_volume_geometry(odet)
+    angles = [3.5, 91.25, 200.0, 359.9]
+    projs = [oracle.lcg_projection(64, 48, i) for i in range(4)]
+    want = np.zeros((61, 67, 67), np.float32)
+    d_v = be.make_volume_device(67, 67, 61)
+    for i, p in enumerate(projs):
+        s, c, ds, dt = oracle.backproject_constants(odet, i, True, angles[i])
+        oracle.backproject(want, p, 0, odet, ovg, s, c, ds, dt)
+        d_p = to_device(be, p, idx=i, phi=angles[i])
+        B.backproject(be, d_p, d_v, 0, det, vg, True, False, None)
+        be.free(d_p)
+    assert_bit_equal(volume_to_host(be, d_v), want)
+    be.free(d_v)
+
+
+def test_backproject_batch_equals_sequence(be, oracle, kat_golden):
+    det = B.DetectorGeometry(*KAT)
+    vg = B.calculate_volume_geometry(det)
+    f = kat_golden["filtered"]
+    n, rows, cols = f.shape
+    stack = be.make_projection_device(cols, rows * n)  # n projections back to back, one pitch
+    h = B.Projection(np.ascontiguousarray(f.reshape(n * rows, cols)), cols, rows * n)
+    be.copy_h2d(h, stack)
+    sc = [B.stage_angle(det, i) for i in range(n)]
+    d_v = be.make_volume_device(67, 67, 61)
+    be.backproject_batch(stack.ptr, stack.pitch, stack.pitch * rows, n, cols, rows, d_v, 0, det, vg, False, None,
+                         [s for s, _ in sc], [c for _, c in sc], det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
+    assert_bit_equal(volume_to_host(be, d_v), kat_golden["volume"])
+    be.free(d_v)
+    be.free(stack)
+
+
+# ---- the whole hot path ------------------------------------------------------------------------------------------
+
+def test_pipeline_against_oracle(be, oracle, kat_golden):
+    """weight -> filter -> backproject on the GPU vs the oracle's pipeline. The only difference is FFT rounding in
+    the filter, which the (linear) backprojection carries through: same tolerance as the filter."""
+    det = B.DetectorGeometry(*KAT)
+    vg = B.calculate_volume_geometry(det)
+    d_v = be.make_volume_device(67, 67, 61)
+    for i in range(8):
+        d_p = to_device(be, oracle.lcg_projection(64, 48, i), idx=i)
+        B.weight(be, d_p, det)
+        B.filter(be, d_p, det)
+        B.backproject(be, d_p, d_v, 0, det, vg, False, False, None)
+        be.free(d_p)
+    got = volume_to_host(be, d_v)
+    want = kat_golden["volume"]
+    assert np.max(np.abs(got - want)) <= FILTER_TOL * np.abs(want).max()
+    assert rel_l2(got, want) <= FILTER_TOL
+    be.free(d_v)
+
+
+# ---- properties at bench-like sizes ---------------------------------------------------------------------------------
+
+def test_large_slab_properties(be, oracle):
+    """1024 x 1024 detector, 1024 x 1024 x 96 slab of the 1024^3 grid (BASELINE config C2 geometry):
+    (a) a crop computed by the oracle (through its ROI path) equals the GPU's voxels bit for bit;
+    (b) two z-slabs with offsets equal the single run (slab identity);
+    (c) backprojecting 2p gives exactly 2x the voxels of backprojecting p (power-of-two scaling is exact)."""
+    n = 1024
+    g = (n, n, 0.2, 0.2, 0, 0, 500, 500, 360.0 / 720)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    vg, ovg = B.calculate_volume_geometry(det), oracle.calculate_volume_geometry(odet)
+    assert (vg.dim_x, vg.dim_y) == (n, n)
+    z0, nz = 400, 96
+    idxs = (0, 77, 400)
+    projs = [oracle.lcg_projection(n, n, i) - np.float32(0.5) for i in idxs]
+
+    def run(scale, z_first, z_count):
+        d_v = be.make_volume_device(n, n, z_count)
+        for i, p in zip(idxs, projs):
+            d_p = to_device(be, p * np.float32(scale), idx=i)
+            B.backproject(be, d_p, d_v, z_first, det, vg, False, False, None)
+            be.free(d_p)
+        out = volume_to_host(be, d_v)
+        be.free(d_v)
+        return out
+
+    full = run(1.0, z0, nz)
+    # (a) oracle crops: centre, an x/y edge, a corner
+    for (x1, y1, z1) in ((480, 500, 40), (0, 300, 0), (960, 960, 64)):
+        roi = oracle.RegionOfInterest(x1, x1 + 64, y1, y1 + 64, z0 + z1, z0 + z1 + 16)
+        want = np.zeros((16, 64, 64), np.float32)
+        for i, p in zip(idxs, projs):
+            s, c, ds, dt = oracle.backproject_constants(odet, i)
+            oracle.backproject(want, p, 0, odet, ovg, s, c, ds, dt, roi)
+        assert_bit_equal(full[z1:z1 + 16, y1:y1 + 64, x1:x1 + 64], want)
+    # (b)
+    lo = run(1.0, z0, 40)
+    hi = run(1.0, z0 + 40, nz - 40)
+    assert_bit_equal(np.concatenate([lo, hi]), full)
+    # (c)
+    assert_bit_equal(run(2.0, z0, nz), full * np.float32(2.0))
+
+
+def test_torch_memory_interop(be, oracle, kat_golden):
+    """PyTorch as plumbing: volume and projections owned by torch tensors, kernels enqueued on torch's stream."""
+    torch = pytest.importorskip("torch")
+    det = B.DetectorGeometry(*KAT)
+    vg = B.calculate_volume_geometry(det)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    tb = B.Backend(0, stream=stream, synchronous=False)
+    vol = torch.zeros((61, 67, 67), dtype=torch.float32, device=dev)
+    v = tb.wrap_volume(vol.data_ptr(), 67, 67, 61, owner=vol)
+    for i in range(8):
+        t = torch.from_numpy(kat_golden["filtered"][i]).to(dev)
+        p = tb.wrap_projection(t.data_ptr(), t.stride(0) * 4, 64, 48, idx=i, owner=t)
+        B.backproject(tb, p, v, 0, det, vg, False, False, None)
+    torch.cuda.synchronize()
+    assert_bit_equal(vol.cpu().numpy(), kat_golden["volume"])
+    tb.close()

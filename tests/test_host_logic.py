@@ -1,0 +1,118 @@
+"""CPU-side checks of the product's host code: the C-ABI library loads and exports every symbol that
+include/paris_hip.h declares, the stage-wrapper constants and geometry agree with the oracle, and the error
+behaviour without a GPU is loud. No compute calls are made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from paris_amd import _lib
+from paris_amd import backend as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "paris_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(paris_hip_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libparis_hip.so lacks %s" % n
+
+
+def test_python_signatures_cover_the_header():
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_struct_layouts_match_the_reference_types():
+    assert C.sizeof(B.DetectorGeometry) == 2 * 4 + 7 * 4  # src/geometry.h:30-46
+    assert C.sizeof(B.VolumeGeometry) == 6 * 4            # :48-57
+    assert C.sizeof(B.SubvolumeGeometry) == 4 * 4         # :59-69
+    assert C.sizeof(B.RegionOfInterest) == 6 * 4          # src/region_of_interest.h:30-38
+    assert C.sizeof(B.SubvolumeInfo) == 5 * 4             # src/subvolume_information.h:30-34
+
+
+GEOMETRIES = [
+    (64, 48, 0.2, 0.25, 1.5, -0.75, 100, 200, 45),
+    (512, 512, 0.2, 0.2, 0, 0, 500, 500, 1.0),
+    (1024, 1024, 0.2, 0.2, 0, 0, 500, 500, 0.5),
+    (2048, 2048, 0.2, 0.2, 0, 0, 500, 500, 0.25),
+    (333, 217, 0.127, 0.254, -3.25, 2.5, 321.5, 123.25, 0.7),
+]
+
+
+@pytest.mark.parametrize("g", GEOMETRIES)
+def test_volume_geometry_matches_oracle(oracle, g):
+    a = B.calculate_volume_geometry(B.DetectorGeometry(*g))
+    b = oracle.calculate_volume_geometry(oracle.DetectorGeometry(*g))
+    assert (a.dim_x, a.dim_y, a.dim_z) == (b.dim_x, b.dim_y, b.dim_z)
+    assert (a.l_vx_x, a.l_vx_y, a.l_vx_z) == (b.l_vx_x, b.l_vx_y, b.l_vx_z)
+
+
+def test_natural_volume_sizes_of_the_bench_configs():
+    for n in (1024, 2048):
+        vg = B.calculate_volume_geometry(B.DetectorGeometry(n, n, 0.2, 0.2, 0, 0, 500, 500, 360.0 / n))
+        assert (vg.dim_x, vg.dim_y) == (n, n)
+
+
+def test_apply_roi_matches_oracle(oracle):
+    vg = B.calculate_volume_geometry(B.DetectorGeometry(*GEOMETRIES[0]))
+    og = oracle.calculate_volume_geometry(oracle.DetectorGeometry(*GEOMETRIES[0]))
+    for roi in ((8, 40, 4, 36, 10, 30), (0, 40, 0, 36, 0, 30), (40, 8, 4, 36, 10, 30), (0, 67, 4, 36, 10, 30),
+                (1, 67, 1, 67, 1, 61)):
+        a = B.apply_roi(vg, *roi)
+        b = oracle.apply_roi(og, oracle.RegionOfInterest(*roi))
+        assert (a.dim_x, a.dim_y, a.dim_z) == (b.dim_x, b.dim_y, b.dim_z)
+
+
+def test_filter_size_matches_oracle(oracle):
+    for n in (1, 2, 3, 64, 65, 512, 1000, 1024, 1025, 2048, 4096):
+        assert B.filter_size(n) == oracle.filter_size(n)
+
+
+@pytest.mark.parametrize("g", GEOMETRIES)
+def test_stage_angle_matches_oracle(oracle, g):
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    for idx in (0, 1, 7, 90, 359, 1439):
+        s, c = B.stage_angle(det, idx)
+        os_, oc, _, _ = oracle.backproject_constants(odet, idx)
+        assert (s, c) == (os_, oc)
+    s, c = B.stage_angle(det, 5, True, 33.25)
+    os_, oc, _, _ = oracle.backproject_constants(odet, 5, True, 33.25)
+    assert (s, c) == (os_, oc)
+
+
+def test_no_device_is_reported_loudly():
+    if B.get_devices():
+        pytest.skip("a GPU is present")
+    with pytest.raises(B.ParisHipError) as e:
+        B.Backend(0)
+    assert e.value.status == _lib.ERROR_NO_DEVICE
+
+
+def test_invalid_arguments():
+    L = _lib.load()
+    assert L.paris_hip_device_count(None) == _lib.ERROR_INVALID_ARGUMENT
+    assert L.paris_hip_ctx_create(0, None, 0, None) == _lib.ERROR_INVALID_ARGUMENT
+    assert L.paris_hip_ctx_destroy(None) == _lib.SUCCESS
+    assert L.paris_hip_weight(None, None, 0, 0, 0, 0, 0, 0, 0, 0) == _lib.ERROR_INVALID_ARGUMENT
+    assert L.paris_hip_calculate_volume_geometry(None, None) == _lib.ERROR_INVALID_ARGUMENT
+    assert b"invalid argument" in L.paris_hip_strerror(_lib.ERROR_INVALID_ARGUMENT)
+
+
+def test_product_does_not_import_the_oracle():
+    """The product path must not route through oracle/ (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "paris_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower().replace("# noqa", ""), os.path.join(dirpath, f)
