@@ -215,6 +215,9 @@ int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant);
  * the volume's alignment), unroll: z slices in flight per lane (1, 2, 4), tz: slices per tile, lds_bytes: LDS
  * budget per workgroup for the staged detector box (1024..65536). Results do not depend on any of them. */
 int paris_hip_set_backproject_tuning(paris_hip_ctx* ctx, int vx, int unroll, int tz, int lds_bytes);
+/* Workgroup -> tile order (-1 default, 0 x-fastest, 1 z-fastest, 5 one contiguous band per XCD) and the cache
+ * policy of the volume stream (1 nontemporal, 0 default, -1 library default). Performance only. */
+int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, int nontemporal);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,7 @@ SIGNATURES = {
     "paris_hip_backproject_timing_collect": (C.c_int, [_vp, _P(_f), _u32, _P(_u32)]),
     "paris_hip_set_backproject_variant": (C.c_int, [_vp, C.c_int]),
     "paris_hip_set_backproject_tuning": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "paris_hip_set_backproject_order": (C.c_int, [_vp, C.c_int, C.c_int]),
 }
 
 _lib = None

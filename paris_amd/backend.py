@@ -239,6 +239,9 @@ class Backend:
     def set_backproject_variant(self, variant):
         check(self._L.paris_hip_set_backproject_variant(self._ctx, variant), "paris_hip_set_backproject_variant")
 
+    def set_backproject_order(self, order=-1, nontemporal=-1):
+        check(self._L.paris_hip_set_backproject_order(self._ctx, order, nontemporal), "paris_hip_set_backproject_order")
+
     def set_backproject_tuning(self, vx=0, unroll=0, tz=0, lds_bytes=0):
         check(self._L.paris_hip_set_backproject_tuning(self._ctx, vx, unroll, tz, lds_bytes),
               "paris_hip_set_backproject_tuning")

@@ -41,6 +41,8 @@ struct paris_hip_ctx
     int bp_variant = 0;
     int bp_vx = 0, bp_unroll = 0; // 0 = automatic
     uint32_t bp_tz = 0, bp_lds_bytes = 0;
+    int bp_order = -1; // -1 = default mapping
+    int bp_nt = 1;     // nontemporal volume loads/stores
     bool filter_lds_attr_set = false;
     std::map<uint32_t, paris_hip_fft_plan> plans; // keyed by FFT length
     // K cached by paris_hip_stage_filter (reference: thread_local static in src/filtering.cpp:42)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Sweeps the tuning knobs of the backprojection kernel on one C4-style slab (2048 x 2048 x Z of the 2048^3 grid,
+2048^2 projection) and prints per-launch time and algorithmic GB/s (8 B per voxel-update). GPU box only."""
+import argparse
+import itertools
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from paris_amd import backend as B  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=2048)
+    ap.add_argument("--slices", type=int, default=256)
+    ap.add_argument("--vx", default="4,2,1")
+    ap.add_argument("--unroll", default="1,2,4")
+    ap.add_argument("--tz", default="16,32,64")
+    ap.add_argument("--lds", default="16384,24576,32768")
+    ap.add_argument("--angles", default="0,17,45,90,200")
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--order", default="0,1,5")
+    ap.add_argument("--nt", default="0,1")
+    args = ap.parse_args()
+    n = args.n
+    det = B.DetectorGeometry(n, n, 0.2, 0.2, 0, 0, 500, 500, 360.0 / 1440)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
+    be = B.Backend(0, synchronous=False)
+    rng = np.random.default_rng(1)
+    h = B.Projection(rng.random((n, n), dtype=np.float32), n, n)
+    d_p = B.load(be, h)
+    d_v = be.make_volume_device(n, n, args.slices)
+    z_first = (n - args.slices) // 2
+    angles = [int(a) for a in args.angles.split(",")]
+    voxels = float(n) * n * args.slices
+    results = []
+    for vx, un, tz, lds, order, nt in itertools.product(*[[int(x) for x in s.split(",")] for s in (args.vx, args.unroll, args.tz, args.lds, args.order, args.nt)]):
+        be.set_backproject_tuning(vx, un, tz, lds)
+        be.set_backproject_order(order, nt)
+        ms = []
+        for rep in range(args.reps + 1):
+            for a in angles:
+                d_p.idx = a * 4
+                B.backproject(be, d_p, d_v, z_first, det, vg, False, False, None)
+                t = be.last_backproject_ms()
+                if rep > 0:
+                    ms.append(t)
+        avg = sum(ms) / len(ms)
+        r = dict(vx=vx, unroll=un, tz=tz, lds=lds, order=order, nt=nt, ms=avg, ms_min=min(ms), ms_max=max(ms), gbs=8 * voxels / avg / 1e6,
+                 gvox=voxels / avg / 1e6)
+        results.append(r)
+        print(json.dumps(r), flush=True)
+    best = max(results, key=lambda r: r["gbs"])
+    print("BEST", json.dumps(best))
+
+
+if __name__ == "__main__":
+    main()
