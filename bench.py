@@ -53,13 +53,52 @@ def geometry(B, w):
     return det, B.VolumeGeometry(dx, dy, dz, l_vx, l_vx, l_vx)
 
 
+def measured_traffic(w, world):
+    """HBM bytes per backprojection launch from the PMC counters (FETCH_SIZE, WRITE_SIZE; separate rocprofv3
+    --pmc passes, gfx950 correction applied) of the same workload, as committed under profiles/ by
+    tools/pmc_traffic.py. Counters cannot be read from inside this process, so None when no profile matches."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if world == 1 and d.get("workload", "").startswith(w["name"]):
+            best = (d["traffic_bytes_per_launch"], os.path.relpath(path, ROOT))
+    return best if best else (None, None)
+
+
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read().split()[0])
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(w, budget_s):
     """Times the oracle's backprojection on this host's cores: the workload's geometry, a slab of `slices`
     central slices, as many projections as fit the time budget."""
     import numpy as np
 
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     O.lib().po_set_num_threads(cores)
     det = O.DetectorGeometry(w["n_row"], w["n_col"], 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 360.0 / w["n_proj"])
     nat = O.calculate_volume_geometry(det)
@@ -190,6 +229,7 @@ def main():
     updates_all = voxels_all * args.batch * args.steps
 
     if rank == 0:
+        traffic, traffic_src = measured_traffic(w, world)
         avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         algo_bytes = 8.0 * voxels_rank + 4.0 * n_row * n_col  # per launch: RMW of the slab + one projection pass
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -216,7 +256,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel": "bp_tile_kernel (one projection per launch, 8 B per voxel-update)",
                 "launches_timed": len(kernel_ms),
             },

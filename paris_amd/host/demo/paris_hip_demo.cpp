@@ -1,0 +1,151 @@
+// A PARIS-style driver over the C++ backend mirror: the per-device loop of src/main.cpp:79-109 with the file
+// stages replaced by raw float32 files, so tests can feed known projections and compare the volume.
+//
+// usage: paris_hip_demo <n_row> <n_col> <l_px_row> <l_px_col> <delta_s> <delta_t> <d_so> <d_od> <delta_phi>
+//                       <n_proj> <in.raw | lcg> <out.raw> [--no-weight] [--no-filter]
+//                       [--slabs N] [--roi x1 x2 y1 y2 z1 z2] [--vol dx dy dz l_vx]
+// in.raw holds n_proj frames of n_col x n_row float32; "lcg" generates the SURVEY.md 8c noise frames.
+// out.raw receives the whole (ROI) volume, slabs written at their slice offsets (fixing SURVEY.md Q4).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "paris/stages.h"
+
+namespace
+{
+    void lcg_fill(float* p, std::size_t n, std::uint32_t idx)
+    {
+        std::uint32_t s = 12345u + idx;
+        for(std::size_t i = 0; i < n; ++i)
+        {
+            s = s * 1664525u + 1013904223u;
+            p[i] = static_cast<float>(s >> 8) / 16777216.f;
+        }
+    }
+}
+
+int main(int argc, char** argv)
+{
+    if(argc < 13)
+    {
+        std::fprintf(stderr, "usage: see the header of paris_hip_demo.cpp\n");
+        return 2;
+    }
+    try
+    {
+        auto det = paris::detector_geometry{};
+        det.n_row = static_cast<std::uint32_t>(std::atoi(argv[1]));
+        det.n_col = static_cast<std::uint32_t>(std::atoi(argv[2]));
+        det.l_px_row = std::strtof(argv[3], nullptr);
+        det.l_px_col = std::strtof(argv[4], nullptr);
+        det.delta_s = std::strtof(argv[5], nullptr);
+        det.delta_t = std::strtof(argv[6], nullptr);
+        det.d_so = std::strtof(argv[7], nullptr);
+        det.d_od = std::strtof(argv[8], nullptr);
+        det.delta_phi = std::strtof(argv[9], nullptr);
+        const auto n_proj = static_cast<std::uint32_t>(std::atoi(argv[10]));
+        const auto in_path = std::string{argv[11]};
+        const auto out_path = std::string{argv[12]};
+
+        bool do_weight = true, do_filter = true, enable_roi = false;
+        int slabs = 1;
+        auto roi = paris::region_of_interest{};
+        auto vol_geo = paris::calculate_volume_geometry(det);
+        for(int a = 13; a < argc; ++a)
+        {
+            if(!std::strcmp(argv[a], "--no-weight")) do_weight = false;
+            else if(!std::strcmp(argv[a], "--no-filter")) do_filter = false;
+            else if(!std::strcmp(argv[a], "--slabs") && a + 1 < argc) slabs = std::atoi(argv[++a]);
+            else if(!std::strcmp(argv[a], "--roi") && a + 6 < argc)
+            {
+                enable_roi = true;
+                roi.x1 = std::atoi(argv[a + 1]); roi.x2 = std::atoi(argv[a + 2]);
+                roi.y1 = std::atoi(argv[a + 3]); roi.y2 = std::atoi(argv[a + 4]);
+                roi.z1 = std::atoi(argv[a + 5]); roi.z2 = std::atoi(argv[a + 6]);
+                a += 6;
+            }
+            else if(!std::strcmp(argv[a], "--vol") && a + 4 < argc)
+            {
+                vol_geo.dim_x = std::atoi(argv[a + 1]); vol_geo.dim_y = std::atoi(argv[a + 2]); vol_geo.dim_z = std::atoi(argv[a + 3]);
+                vol_geo.l_vx_x = vol_geo.l_vx_y = vol_geo.l_vx_z = std::strtof(argv[a + 4], nullptr);
+                a += 4;
+            }
+            else
+            {
+                std::fprintf(stderr, "unknown argument %s\n", argv[a]);
+                return 2;
+            }
+        }
+        auto roi_geo = vol_geo;
+        if(enable_roi)
+            roi_geo = paris::apply_roi(vol_geo, roi.x1, roi.x2, roi.y1, roi.y2, roi.z1, roi.z2); // src/main.cpp:125-130
+
+        auto devices = paris::backend::get_devices();
+        if(devices.empty())
+            throw paris::stage_construction_error{"no HIP device"};
+        paris::backend::set_device(devices[0]); // src/main.cpp:87
+
+        // fixed slab count (the memory-driven count is backend::make_subvolume_information)
+        auto info = paris::subvolume_info{};
+        info.num = slabs < 1 ? 1 : slabs;
+        info.geo = {roi_geo.dim_x, roi_geo.dim_y, roi_geo.dim_z / static_cast<std::uint32_t>(info.num),
+                    roi_geo.dim_z % static_cast<std::uint32_t>(info.num)};
+
+        // all frames in host memory (the reference re-reads them per task: src/main.cpp:93)
+        const auto frame = std::size_t{det.n_row} * det.n_col;
+        auto frames = std::vector<float>(frame * n_proj);
+        if(in_path == "lcg")
+            for(std::uint32_t i = 0; i < n_proj; ++i)
+                lcg_fill(frames.data() + frame * i, frame, i);
+        else
+        {
+            std::FILE* f = std::fopen(in_path.c_str(), "rb");
+            if(f == nullptr || std::fread(frames.data(), sizeof(float), frames.size(), f) != frames.size())
+                throw paris::stage_runtime_error{"cannot read " + in_path};
+            std::fclose(f);
+        }
+
+        std::FILE* out = std::fopen(out_path.c_str(), "wb");
+        if(out == nullptr)
+            throw paris::stage_runtime_error{"cannot open " + out_path};
+
+        for(int id = 0; id < info.num; ++id) // one task per slab: src/task.cpp:38-48, src/main.cpp:89-108
+        {
+            const bool last = (info.num - id) <= 1;
+            auto v = paris::make_volume(info.geo, last);
+            const auto offset = static_cast<std::uint32_t>(id) * info.geo.dim_z;
+            for(std::uint32_t i = 0; i < n_proj; ++i)
+            {
+                auto p = paris::backend::make_projection_host(det.n_row, det.n_col);
+                std::memcpy(p.buf.get(), frames.data() + frame * i, frame * sizeof(float));
+                p.idx = i;
+                auto d_p = paris::load(p);
+                if(do_weight) paris::weight(d_p, det);
+                if(do_filter) paris::filter(d_p, det);
+                paris::backproject(d_p, v, offset, det, vol_geo, false, enable_roi, roi);
+            }
+            auto h_v = paris::backend::make_volume_host(v.dim_x, v.dim_y, v.dim_z);
+            paris::backend::copy_d2h(v, h_v);
+            const auto n = std::size_t{v.dim_x} * v.dim_y * v.dim_z;
+            std::fseek(out, static_cast<long>(std::size_t{v.dim_x} * v.dim_y * offset * sizeof(float)), SEEK_SET);
+            if(std::fwrite(h_v.buf.get(), sizeof(float), n, out) != n)
+                throw paris::stage_runtime_error{"short write"};
+        }
+        std::fclose(out);
+        std::printf("ok %u %u %u\n", roi_geo.dim_x, roi_geo.dim_y, roi_geo.dim_z);
+        return 0;
+    }
+    catch(const paris::stage_construction_error& e)
+    {
+        std::fprintf(stderr, "pipeline construction failed: %s\n", e.what());
+        return 1;
+    }
+    catch(const paris::stage_runtime_error& e)
+    {
+        std::fprintf(stderr, "pipeline execution failed: %s\n", e.what());
+        return 1;
+    }
+}

@@ -1,0 +1,238 @@
+// namespace paris::hip -- the MI355X backend behind the PARIS backend surface.
+//
+// Same types and the same 14 free functions as src/openmp/backend.h:42-89 / src/cuda/backend.h:50-103 (cleanest
+// statement: src/generic/backend.h:54-88), implemented over the C ABI of include/paris_hip.h. A maintainer adds
+//     #elif defined(PARIS_ENABLE_HIP)
+//     #include "hip/backend.h"          // + `namespace backend = hip;` in the alias block
+// to src/backend.h:26-47.
+//
+// Per-device state: the reference binds a host thread to a device with set_device() and keeps everything else
+// in thread_local statics. Here set_device() creates (once per thread and device) the paris_hip_ctx that holds
+// that state; every other function uses the calling thread's current ctx. Calls are synchronous, like the
+// reference's. A non-zero C status becomes stage_runtime_error (stage_construction_error for allocation and
+// subvolume planning), after which the reference's main() aborts (src/main.cpp:181-192).
+#ifndef PARIS_AMD_HOST_HIP_BACKEND_H_
+#define PARIS_AMD_HOST_HIP_BACKEND_H_
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../types.h"
+
+namespace paris
+{
+    namespace hip
+    {
+        using device_handle = int;
+
+        namespace detail
+        {
+            struct ctx_deleter { void operator()(paris_hip_ctx* c) const noexcept { paris_hip_ctx_destroy(c); } };
+
+            struct thread_state
+            {
+                std::map<device_handle, std::unique_ptr<paris_hip_ctx, ctx_deleter>> per_device;
+                paris_hip_ctx* current = nullptr;
+            };
+
+            inline auto state() -> thread_state&
+            {
+                thread_local thread_state s;
+                return s;
+            }
+
+            inline void runtime_check(int rc, const char* what)
+            {
+                if(rc != PARIS_HIP_SUCCESS)
+                    throw stage_runtime_error{std::string{what} + " failed: " + paris_hip_strerror(rc)};
+            }
+
+            inline void construction_check(int rc, const char* what)
+            {
+                if(rc != PARIS_HIP_SUCCESS)
+                    throw stage_construction_error{std::string{what} + " failed: " + paris_hip_strerror(rc)};
+            }
+        }
+
+        // ---- device management (src/cuda/device.cpp:31-47) --------------------------------------------------
+        inline auto get_devices() -> std::vector<device_handle>
+        {
+            int n = 0;
+            detail::construction_check(paris_hip_device_count(&n), "get_devices()");
+            auto v = std::vector<device_handle>{};
+            for(int d = 0; d < n; ++d)
+                v.push_back(d);
+            return v;
+        }
+
+        inline auto set_device(device_handle& d) -> int
+        {
+            auto& s = detail::state();
+            auto it = s.per_device.find(d);
+            if(it == s.per_device.end())
+            {
+                paris_hip_ctx* c = nullptr;
+                detail::construction_check(paris_hip_ctx_create(d, nullptr, PARIS_HIP_CTX_SYNCHRONOUS, &c), "set_device()");
+                it = s.per_device.emplace(d, std::unique_ptr<paris_hip_ctx, detail::ctx_deleter>{c}).first;
+            }
+            s.current = it->second.get();
+            return 0;
+        }
+
+        inline auto current_ctx() -> paris_hip_ctx*
+        {
+            auto& s = detail::state();
+            if(s.current == nullptr)
+            {
+                auto d = device_handle{0}; // the reference's single-device path never calls set_device explicitly
+                set_device(d);
+            }
+            return s.current;
+        }
+
+        // ---- buffers ------------------------------------------------------------------------------------------
+        struct device_free { void operator()(float* p) const noexcept { paris_hip_free(current_ctx(), p); } };
+        struct host_free { void operator()(float* p) const noexcept { paris_hip_free_host(current_ctx(), p); } };
+
+        // device projection buffer with a row pitch in bytes, like cuda::pitched_device_ptr
+        class pitched_buffer
+        {
+        public:
+            pitched_buffer() noexcept = default;
+            pitched_buffer(float* p, std::size_t pitch_bytes) noexcept : ptr_{p}, pitch_{pitch_bytes} {}
+            auto get() const noexcept -> float* { return ptr_.get(); }
+            auto pitch() const noexcept -> std::size_t { return pitch_; }
+            explicit operator bool() const noexcept { return static_cast<bool>(ptr_); }
+        private:
+            std::unique_ptr<float, device_free> ptr_{};
+            std::size_t pitch_ = 0;
+        };
+
+        using projection_host_buffer_type = std::unique_ptr<float, host_free>;
+        using projection_device_buffer_type = pitched_buffer;
+        using volume_host_buffer_type = std::unique_ptr<float, host_free>;
+        using volume_device_buffer_type = std::unique_ptr<float, device_free>;
+        using filter_buffer_type = std::unique_ptr<float, device_free>;
+
+        struct metadata {};
+
+        using projection_host_type = projection<projection_host_buffer_type, metadata>;
+        using projection_device_type = projection<projection_device_buffer_type, metadata>;
+        using volume_host_type = volume<volume_host_buffer_type>;
+        using volume_device_type = volume<volume_device_buffer_type>;
+
+        // ---- memory (src/cuda/memory.cpp:33-102) ------------------------------------------------------------------
+        inline auto make_projection_host(std::uint32_t dim_x, std::uint32_t dim_y) -> projection_host_type
+        {
+            void* p = nullptr;
+            detail::construction_check(paris_hip_malloc_host(current_ctx(), std::size_t{dim_x} * dim_y * sizeof(float), &p),
+                                       "make_projection_host()");
+            return {projection_host_buffer_type{static_cast<float*>(p)}, dim_x, dim_y, 0, 0.f, metadata{}};
+        }
+
+        inline auto make_projection_device(std::uint32_t dim_x, std::uint32_t dim_y) -> projection_device_type
+        {
+            float* p = nullptr;
+            std::size_t pitch = 0;
+            detail::construction_check(paris_hip_malloc_projection(current_ctx(), dim_x, dim_y, &p, &pitch),
+                                       "make_projection_device()");
+            return {pitched_buffer{p, pitch}, dim_x, dim_y, 0, 0.f, metadata{}};
+        }
+
+        inline auto make_volume_host(std::uint32_t dim_x, std::uint32_t dim_y, std::uint32_t dim_z) -> volume_host_type
+        {
+            const auto n = std::size_t{dim_x} * dim_y * dim_z;
+            void* p = nullptr;
+            detail::construction_check(paris_hip_malloc_host(current_ctx(), n * sizeof(float), &p), "make_volume_host()");
+            auto f = static_cast<float*>(p);
+            for(std::size_t i = 0; i < n; ++i)
+                f[i] = 0.f; // zero-filled like src/openmp/memory.cpp:46-47
+            return {volume_host_buffer_type{f}, dim_x, dim_y, dim_z, 0};
+        }
+
+        inline auto make_volume_device(std::uint32_t dim_x, std::uint32_t dim_y, std::uint32_t dim_z) -> volume_device_type
+        {
+            float* p = nullptr;
+            detail::construction_check(paris_hip_malloc_volume(current_ctx(), dim_x, dim_y, dim_z, &p), "make_volume_device()");
+            return {volume_device_buffer_type{p}, dim_x, dim_y, dim_z, 0};
+        }
+
+        inline auto copy_h2d(const projection_host_type& h_p, projection_device_type& d_p) -> void
+        {
+            detail::runtime_check(paris_hip_memcpy_projection_h2d(current_ctx(), d_p.buf.get(), d_p.buf.pitch(), h_p.buf.get(),
+                                                                  std::size_t{h_p.dim_x} * sizeof(float), h_p.dim_x, h_p.dim_y),
+                                  "copy_h2d(projection)");
+            d_p.idx = h_p.idx; // src/openmp/memory.cpp:60-62
+            d_p.phi = h_p.phi;
+            d_p.meta = h_p.meta;
+        }
+
+        inline auto copy_d2h(const projection_device_type& d_p, projection_host_type& h_p) -> void
+        {
+            detail::runtime_check(paris_hip_memcpy_projection_d2h(current_ctx(), h_p.buf.get(), std::size_t{h_p.dim_x} * sizeof(float),
+                                                                  d_p.buf.get(), d_p.buf.pitch(), d_p.dim_x, d_p.dim_y),
+                                  "copy_d2h(projection)");
+            h_p.idx = d_p.idx;
+            h_p.phi = d_p.phi;
+            h_p.meta = d_p.meta;
+        }
+
+        inline auto copy_h2d(const volume_host_type& h_v, volume_device_type& d_v) -> void
+        {
+            detail::runtime_check(paris_hip_memcpy_volume_h2d(current_ctx(), d_v.buf.get(), h_v.buf.get(), h_v.dim_x, h_v.dim_y, h_v.dim_z),
+                                  "copy_h2d(volume)");
+            d_v.off = h_v.off; // src/openmp/memory.cpp:73
+        }
+
+        inline auto copy_d2h(const volume_device_type& d_v, volume_host_type& h_v) -> void
+        {
+            detail::runtime_check(paris_hip_memcpy_volume_d2h(current_ctx(), h_v.buf.get(), d_v.buf.get(), d_v.dim_x, d_v.dim_y, d_v.dim_z),
+                                  "copy_d2h(volume)");
+            h_v.off = d_v.off;
+        }
+
+        // ---- subvolume planning (src/cuda/subvolume_information.cpp:63-118) ---------------------------------------
+        inline auto make_subvolume_information(const volume_geometry& vol_geo, const detector_geometry& det_geo) -> subvolume_info
+        {
+            subvolume_info info{};
+            detail::construction_check(paris_hip_make_subvolume_information(&vol_geo, &det_geo, 0, &info),
+                                       "make_subvolume_information()");
+            return info;
+        }
+
+        // ---- the numeric stages ---------------------------------------------------------------------------------------
+        inline auto weight(projection_device_type& p, float h_min, float v_min, float d_sd, float l_px_row, float l_px_col) -> void
+        {
+            detail::runtime_check(paris_hip_weight(current_ctx(), p.buf.get(), p.buf.pitch(), p.dim_x, p.dim_y, h_min, v_min, d_sd,
+                                                   l_px_row, l_px_col), "weight()");
+        }
+
+        inline auto make_filter(std::uint32_t size, float tau) -> filter_buffer_type
+        {
+            float* k = nullptr;
+            detail::construction_check(paris_hip_make_filter(current_ctx(), size, tau, &k), "make_filter()");
+            return filter_buffer_type{k};
+        }
+
+        inline auto apply_filter(projection_device_type& p, const filter_buffer_type& k, std::uint32_t filter_size,
+                                 std::uint32_t n_col) -> void
+        {
+            detail::runtime_check(paris_hip_apply_filter(current_ctx(), p.buf.get(), p.buf.pitch(), p.dim_x, p.dim_y, k.get(),
+                                                         filter_size, n_col), "apply_filter()");
+        }
+
+        inline auto backproject(const projection_device_type& p, volume_device_type& v, std::uint32_t v_offset,
+                                const detector_geometry& det_geo, const volume_geometry& vol_geo, bool enable_roi,
+                                const region_of_interest& roi, float sin, float cos, float delta_s, float delta_t) -> void
+        {
+            detail::runtime_check(paris_hip_backproject(current_ctx(), p.buf.get(), p.buf.pitch(), p.dim_x, p.dim_y, v.buf.get(),
+                                                        v.dim_x, v.dim_y, v.dim_z, v_offset, &det_geo, &vol_geo, enable_roi ? 1 : 0,
+                                                        &roi, sin, cos, delta_s, delta_t), "backproject()");
+        }
+    }
+}
+
+#endif

@@ -1,0 +1,87 @@
+"""The N > 1 path on CPU: world_size-2 gloo ranks each reconstruct their z-slab (paris_amd.sharding, the rule bench.py
+uses) with the oracle standing in for the GPU kernels, then gather on rank 0 and compare with the single-rank
+volume. Checks the partition (remainder on the last slab, offsets) and the barrier / max-over-ranks timing idiom."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, dim_z_override, result_path):
+    sys.path.insert(0, ROOT)
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle as O
+    from paris_amd import backend as B
+    from paris_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = (64, 48, 0.2, 0.25, 1.5, -0.75, 100, 200, 45)
+    det, odet = B.DetectorGeometry(*g), O.DetectorGeometry(*g)
+    vg = B.calculate_volume_geometry(det)
+    ovg = O.calculate_volume_geometry(odet)
+    info = sharding.make_subvolume_info(vg, world)
+    z_first, z_count = sharding.slab_of_task(info, rank)
+
+    dist.barrier()
+    t0 = time.perf_counter()
+    slab = O.reconstruct(odet, ovg, 4, v_dims=(z_count, vg.dim_y, vg.dim_x), v_offset=z_first)
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+
+    # final gather (the only cross-rank step the path has): ragged slabs -> padded gather on rank 0
+    pad = info.geo.dim_z + info.geo.remainder
+    mine = torch.zeros((pad, vg.dim_y, vg.dim_x))
+    mine[:z_count] = torch.from_numpy(slab)
+    parts = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, parts, dst=0)
+    if rank == 0:
+        full = np.zeros((vg.dim_z, vg.dim_y, vg.dim_x), np.float32)
+        for r in range(world):
+            zf, zc = sharding.slab_of_task(info, r)
+            full[zf:zf + zc] = parts[r][:zc].numpy()
+        want = O.reconstruct(odet, ovg, 4)
+        np.save(result_path, np.array([float(np.array_equal(full, want)), float(elapsed.item())]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_sharding_matches_single_rank(tmp_path, world):
+    import torch.multiprocessing as mp
+    result = str(tmp_path / "r.npy")
+    mp.spawn(_worker, args=(world, _free_port(), None, result), nprocs=world, join=True)
+    ok, elapsed = np.load(result)
+    assert ok == 1.0 and elapsed > 0
+
+
+def test_partition_rule():
+    sys.path.insert(0, ROOT)
+    from paris_amd import backend as B
+    from paris_amd import sharding
+    vg = B.VolumeGeometry(8, 8, 61, 1, 1, 1)
+    info = sharding.make_subvolume_info(vg, 8)
+    assert (info.num, info.geo.dim_z, info.geo.remainder) == (8, 7, 5)  # src/cuda/subvolume_information.cpp:112-116
+    slabs = [sharding.slab_of_task(info, t) for t in range(8)]
+    assert slabs[0] == (0, 7) and slabs[7] == (49, 12)                   # last slab takes the remainder
+    assert sum(c for _, c in slabs) == 61
+    assert sharding.tasks_of_rank(info, 1, 2) == [1, 3, 5, 7]
+    one = sharding.make_subvolume_info(vg, 1)
+    assert sharding.slab_of_task(one, 0) == (0, 61)
+    with pytest.raises(ValueError):
+        sharding.slab_of_task(info, 8)

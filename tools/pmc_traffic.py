@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --output-format csv) of bench.py into the per-launch HBM
+traffic record bench.py reports as roofline.traffic.
+
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- python3 bench.py --steps 1 --warmup 1 --batch 2 --cpu-budget 0
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- python3 bench.py --steps 1 --warmup 1 --batch 2 --cpu-budget 0
+  python tools/pmc_traffic.py gpurun_out/prof_fetch gpurun_out/prof_write "<workload name>" profiles/rNN_pmc_traffic_c3.json
+
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM): both counters are in KiB; on gfx950
+FETCH_SIZE counts exactly half the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact.
+"""
+import csv
+import glob
+import json
+import sys
+
+
+def values(d, counter):
+    f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+            if "bp_tile" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+
+
+def main():
+    fetch_dir, write_dir, workload, out_path = sys.argv[1:5]
+    fetch, write = values(fetch_dir, "FETCH_SIZE"), values(write_dir, "WRITE_SIZE")
+    launches = [{"FETCH_SIZE_KiB": a, "WRITE_SIZE_KiB": b, "fetch_bytes_corrected": a * 2048, "write_bytes": b * 1024,
+                 "hbm_bytes": a * 2048 + b * 1024} for a, b in zip(fetch, write)]
+    out = {"workload": workload, "kernel": "bp_tile_kernel, one projection per launch", "launches": launches,
+           "traffic_bytes_per_launch": sum(l["hbm_bytes"] for l in launches) / len(launches),
+           "note": "FETCH_SIZE x 1024 x 2 (gfx950 half-count of wide streaming reads) + WRITE_SIZE x 1024"}
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(out["traffic_bytes_per_launch"])
+
+
+if __name__ == "__main__":
+    main()
