@@ -218,6 +218,14 @@ int paris_hip_set_backproject_tuning(paris_hip_ctx* ctx, int vx, int unroll, int
 /* Workgroup -> tile order (-1 default, 0 x-fastest, 1 z-fastest, 5 one contiguous band per XCD) and the cache
  * policy of the volume stream (1 nontemporal, 0 default, -1 library default). Performance only. */
 int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, int nontemporal);
+/* The per-voxel division by the detector pixel pitch may run as multiply + 2 FMA instead of the IEEE sequence,
+ * but only for a divisor for which an exhaustive GPU check over all 2^32 fp32 dividends (once per ctx and divisor)
+ * found the detector coordinate v = x / pitch - 0.5 identical (bit for bit, or out of any detector's range both ways).
+ * enable = 0 forces the IEEE sequence. Results never depend on this. */
+int paris_hip_set_backproject_fast_division(paris_hip_ctx* ctx, int enable);
+/* Runs (or looks up) the exhaustive check for one divisor: *exact = 1 when multiply + 2 FMA reproduces
+ * x / divisor - 0.5 for every fp32 x (see above). */
+int paris_hip_fast_division_is_exact(paris_hip_ctx* ctx, float divisor, int* exact);
 
 #ifdef __cplusplus
 }

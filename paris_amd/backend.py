@@ -242,6 +242,15 @@ class Backend:
     def set_backproject_order(self, order=-1, nontemporal=-1):
         check(self._L.paris_hip_set_backproject_order(self._ctx, order, nontemporal), "paris_hip_set_backproject_order")
 
+    def fast_division_is_exact(self, divisor):
+        ok = C.c_int()
+        check(self._L.paris_hip_fast_division_is_exact(self._ctx, divisor, C.byref(ok)), "paris_hip_fast_division_is_exact")
+        return bool(ok.value)
+
+    def set_backproject_fast_division(self, enable=True):
+        check(self._L.paris_hip_set_backproject_fast_division(self._ctx, int(bool(enable))),
+              "paris_hip_set_backproject_fast_division")
+
     def set_backproject_tuning(self, vx=0, unroll=0, tz=0, lds_bytes=0):
         check(self._L.paris_hip_set_backproject_tuning(self._ctx, vx, unroll, tz, lds_bytes),
               "paris_hip_set_backproject_tuning")

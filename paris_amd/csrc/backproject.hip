@@ -19,6 +19,7 @@
 #include "paris_hip_internal.h"
 
 #include <cmath>
+#include <cstring>
 
 namespace
 {
@@ -36,6 +37,7 @@ namespace
         float d_so, d_sd;
         float min_h, min_v; // -(p_dim * l_px/2) - delta
         float l_px_x, l_px_y;
+        float rcp_l_px_y; // RN(1 / l_px_y), used only by the validated fast division
         float p_dim_x_f, p_dim_y_f;
         uint32_t lds_floats;
         uint32_t tz; // slices per tile
@@ -63,10 +65,49 @@ namespace
         return c;
     }
 
+    // x / c for a divisor c that is constant over the launch, with r = RN(1 / c): one multiply and two FMAs
+    // (Markstein's correction step) instead of the ~10-instruction IEEE sequence. Only used after
+    // fastdiv_validate_kernel has checked, for THIS c and EVERY fp32 x, that the result has the bits of x / c.
+    __device__ __forceinline__ float div_by_constant(float x, float c, float r)
+    {
+        const float q = x * r;
+        const float e = __builtin_fmaf(-q, c, x); // exact remainder
+        return __builtin_fmaf(e, r, q);
+    }
+
     // v detector coordinate of slice z_m for a column with magnification `factor` (:130-133, :45-50)
+    template <bool FD>
     __device__ __forceinline__ float v_coordinate(const BpParams& g, float z_m, float factor)
     {
-        return ((z_m * factor) - g.min_v) / g.l_px_y - (1.f / 2.f);
+        const float b = (z_m * factor) - g.min_v;
+        const float q = FD ? div_by_constant(b, g.l_px_y, g.rcp_l_px_y) : b / g.l_px_y;
+        return q - (1.f / 2.f);
+    }
+
+    // Exhaustive check of div_by_constant for one divisor: all 2^32 bit patterns of x. The quotient is consumed
+    // only as v = q - 0.5f (v_coordinate), so a pattern passes when v has the same bits either way, or both are NaN,
+    // or both lie beyond +-2^24 / are non-finite (no detector has 2^24 rows: such a coordinate fails the validity
+    // test either way and the contribution is the same exact 0). In practice the two forms differ only where the
+    // remainder underflows (|x| < 2^-103: v = -0.5 both ways) or the product overflows (|x| > 2^124).
+    __global__ void __launch_bounds__(256) fastdiv_validate_kernel(float c, float r, unsigned long long* mismatches)
+    {
+        const uint32_t t = blockIdx.x * 256u + threadIdx.x; // 2^24 threads x 256 patterns
+        unsigned int bad = 0;
+        for(uint32_t i = 0; i < 256u; ++i)
+        {
+            const uint32_t bits = (i << 24) | t;
+            const float x = __uint_as_float(bits);
+            const float want = x / c - (1.f / 2.f);
+            const float got = div_by_constant(x, c, r) - (1.f / 2.f);
+            const bool same = __float_as_uint(want) == __float_as_uint(got);
+            const bool both_nan = (want != want) && (got != got);
+            const bool want_far = !(fabsf(want) <= 16777216.f); // beyond 2^24, inf or NaN
+            const bool got_far = !(fabsf(got) <= 16777216.f);
+            if(!(same || both_nan || (want_far && got_far)))
+                ++bad;
+        }
+        if(bad)
+            atomicAdd(mismatches, static_cast<unsigned long long>(bad));
     }
 
     __device__ __forceinline__ int to_int_clamped(float x)
@@ -148,7 +189,7 @@ namespace
     // --------------------------------------------------------------------------------------------
     // Tile kernel. 1-D grid over ntx * nty * ntz tiles of 64 x TY x g.tz voxels, TY = 4*VX.
     // --------------------------------------------------------------------------------------------
-    template <int VX, int UNROLL, bool NT>
+    template <int VX, int UNROLL, bool NT, bool FD>
     __global__ void __launch_bounds__(256) bp_tile_kernel(const BpParams g)
     {
         extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -185,8 +226,8 @@ namespace
         }
         const float z_lo = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
         const float z_hi = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
-        const float v00 = v_coordinate(g, z_lo, fmin), v01 = v_coordinate(g, z_lo, fmax);
-        const float v10 = v_coordinate(g, z_hi, fmin), v11 = v_coordinate(g, z_hi, fmax);
+        const float v00 = v_coordinate<false>(g, z_lo, fmin), v01 = v_coordinate<false>(g, z_lo, fmax);
+        const float v10 = v_coordinate<false>(g, z_hi, fmin), v11 = v_coordinate<false>(g, z_hi, fmax);
         const float vmin = fminf(fminf(v00, v01), fminf(v10, v11));
         const float vmax = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
 
@@ -264,7 +305,7 @@ namespace
 #pragma unroll
             for(int j = 0; j < VX; ++j)
             {
-                const float v = v_coordinate(g, z_m, factor[j]);
+                const float v = v_coordinate<FD>(g, z_m, factor[j]);
                 const float y1 = floorf(v);
                 const float y2 = y1 + 1.f;
                 const bool valid = (y1 >= 0.f) && (y2 < ymax[j]); // :67-68 (+ x validity)
@@ -332,7 +373,7 @@ namespace
         const ColConst c = column_constants(g, g.k_off + k, g.l_off + l);
         const float z_m = g.z_base + static_cast<float>(g.m_off + m) * g.l_vx_z;
         const float x = c.h;
-        const float y = v_coordinate(g, z_m, c.factor);
+        const float y = v_coordinate<false>(g, z_m, c.factor);
         const float x1 = floorf(x), x2 = x1 + 1.f, y1 = floorf(y), y2 = y1 + 1.f;
         float interp = 0.f;
         if(x1 >= 0.f && x2 < g.p_dim_x_f && y1 >= 0.f && y2 < g.p_dim_y_f)
@@ -366,7 +407,7 @@ namespace
     constexpr uint32_t LDS_BYTES_DEFAULT = 24u * 1024u;
     constexpr uint32_t LDS_BYTES_MAX = 64u * 1024u;
 
-    template <int VX, int UNROLL, bool NT>
+    template <int VX, int UNROLL, bool NT, bool FD>
     void launch_tile(BpParams& g, hipStream_t stream)
     {
         constexpr uint32_t TY = 4u * VX;
@@ -376,27 +417,57 @@ namespace
         uint32_t blocks = g.ntx * g.nty * g.ntz;
         if(g.order == 5u)
             blocks = ((blocks + 7u) / 8u) * 8u;
-        hipLaunchKernelGGL((bp_tile_kernel<VX, UNROLL, NT>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, g);
+        hipLaunchKernelGGL((bp_tile_kernel<VX, UNROLL, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, g);
     }
 
-    template <int VX, bool NT>
+    template <int VX, bool NT, bool FD>
     void launch_tile_unroll(BpParams& g, int unroll, hipStream_t stream)
     {
         switch(unroll)
         {
-            case 1: launch_tile<VX, 1, NT>(g, stream); break;
-            case 2: launch_tile<VX, 2, NT>(g, stream); break;
-            default: launch_tile<VX, 4, NT>(g, stream); break;
+            case 1: launch_tile<VX, 1, NT, FD>(g, stream); break;
+            case 2: launch_tile<VX, 2, NT, FD>(g, stream); break;
+            default: launch_tile<VX, 4, NT, FD>(g, stream); break;
         }
     }
 
     template <int VX>
-    void launch_tile_nt(BpParams& g, int unroll, bool nt, hipStream_t stream)
+    void launch_tile_flags(BpParams& g, int unroll, bool nt, bool fd, hipStream_t stream)
     {
-        if(nt)
-            launch_tile_unroll<VX, true>(g, unroll, stream);
+        if(nt && fd)
+            launch_tile_unroll<VX, true, true>(g, unroll, stream);
+        else if(nt)
+            launch_tile_unroll<VX, true, false>(g, unroll, stream);
+        else if(fd)
+            launch_tile_unroll<VX, false, true>(g, unroll, stream);
         else
-            launch_tile_unroll<VX, false>(g, unroll, stream);
+            launch_tile_unroll<VX, false, false>(g, unroll, stream);
+    }
+
+    // Is div_by_constant exact for this divisor? Checked once per ctx and divisor on the GPU (about 2 ms).
+    int fastdiv_is_exact(paris_hip_ctx* ctx, float c, bool* ok)
+    {
+        *ok = false;
+        if(!(c > 0.f) || !(c < INFINITY))
+            return PARIS_HIP_SUCCESS;
+        uint32_t key;
+        static_assert(sizeof(key) == sizeof(c), "fp32");
+        std::memcpy(&key, &c, sizeof(key));
+        auto it = ctx->fastdiv_exact.find(key);
+        if(it == ctx->fastdiv_exact.end())
+        {
+            unsigned long long* d_bad = nullptr;
+            PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(*d_bad)));
+            PARIS_HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(*d_bad), ctx->stream));
+            hipLaunchKernelGGL(fastdiv_validate_kernel, dim3(1u << 16), dim3(256), 0, ctx->stream, c, 1.f / c, d_bad);
+            unsigned long long bad = ~0ull;
+            PARIS_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+            PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            PARIS_HIP_TRY(hipFree(d_bad));
+            it = ctx->fastdiv_exact.emplace(key, bad == 0ull).first;
+        }
+        *ok = it->second;
+        return PARIS_HIP_SUCCESS;
     }
 }
 
@@ -449,6 +520,11 @@ extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_
     g.l_px_y = det_geo->l_px_col;
     g.min_h = detector_min(p_dim_x, g.l_px_x, delta_s);
     g.min_v = detector_min(p_dim_y, g.l_px_y, delta_t);
+    g.rcp_l_px_y = 1.f / g.l_px_y;
+    bool fd = false;
+    if(ctx->bp_fastdiv != 0)
+        if(int rc = fastdiv_is_exact(ctx, g.l_px_y, &fd))
+            return rc;
     g.p_dim_x_f = static_cast<float>(p_dim_x);
     g.p_dim_y_f = static_cast<float>(p_dim_y);
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
@@ -478,11 +554,11 @@ extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_
         const int unroll = ctx->bp_unroll ? ctx->bp_unroll : 2;
         const bool nt = ctx->bp_nt != 0;
         if(vx == 4)
-            launch_tile_nt<4>(g, unroll, nt, ctx->stream);
+            launch_tile_flags<4>(g, unroll, nt, fd, ctx->stream);
         else if(vx == 2)
-            launch_tile_nt<2>(g, unroll, nt, ctx->stream);
+            launch_tile_flags<2>(g, unroll, nt, fd, ctx->stream);
         else
-            launch_tile_nt<1>(g, unroll, nt, ctx->stream);
+            launch_tile_flags<1>(g, unroll, nt, fd, ctx->stream);
     }
     PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
     ++ctx->bp_launches;
@@ -545,6 +621,27 @@ extern "C" int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, in
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_order = order;
     ctx->bp_nt = nontemporal < 0 ? 1 : nontemporal;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_fast_division_is_exact(paris_hip_ctx* ctx, float divisor, int* exact)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(exact == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    bool ok = false;
+    if(int rc = fastdiv_is_exact(ctx, divisor, &ok))
+        return rc;
+    *exact = ok ? 1 : 0;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_set_backproject_fast_division(paris_hip_ctx* ctx, int enable)
+{
+    if(ctx == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    ctx->bp_fastdiv = enable ? 1 : 0;
     return PARIS_HIP_SUCCESS;
 }
 

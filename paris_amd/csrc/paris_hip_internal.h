@@ -43,6 +43,8 @@ struct paris_hip_ctx
     uint32_t bp_tz = 0, bp_lds_bytes = 0;
     int bp_order = -1; // -1 = default mapping
     int bp_nt = 1;     // nontemporal volume loads/stores
+    int bp_fastdiv = 1; // use the validated multiply+2 FMA division by the pixel pitch when it is exact
+    std::map<uint32_t, bool> fastdiv_exact; // divisor bits -> exhaustive check result
     bool filter_lds_attr_set = false;
     std::map<uint32_t, paris_hip_fft_plan> plans; // keyed by FFT length
     // K cached by paris_hip_stage_filter (reference: thread_local static in src/filtering.cpp:42)

@@ -245,6 +245,32 @@ def test_backproject_every_kernel_shape_bit_exact(be, oracle, tuning):
     assert_bit_equal(got, want)
 
 
+@pytest.mark.parametrize("fast", [False, True])
+def test_backproject_fast_division_switch(be, oracle, kat_golden, fast):
+    """The multiply + 2 FMA division by the pixel pitch (used only after the exhaustive per-divisor check) and the
+    IEEE sequence give the same bits."""
+    det = B.DetectorGeometry(*KAT)
+    vg = B.calculate_volume_geometry(det)
+    be.set_backproject_fast_division(fast)
+    try:
+        got = hip_backproject_all(be, kat_golden["filtered"], det, vg, (61, 67, 67))
+    finally:
+        be.set_backproject_fast_division(True)
+    assert_bit_equal(got, kat_golden["volume"])
+
+
+def test_fast_division_exhaustive_check(be):
+    """The per-divisor check sweeps all 2^32 dividends on the GPU. Typical pixel pitches pass; whatever it reports,
+    the kernel only uses the fast form when it passed. A divisor the check must reject: 0 / negative / inf."""
+    for c in (0.2, 0.25, 0.127, 0.4, 0.1, 0.05, 1.0, 0.074):
+        assert be.fast_division_is_exact(c) is True, c
+    for c in (0.0, -0.2, float("inf")):
+        assert be.fast_division_is_exact(c) is False
+    # odd divisors: the answer may be either, it just has to come back
+    for c in (float(np.float32(1.0) - np.float32(2.0 ** -24)), 1e-38, 3e38, 1e-42):
+        assert be.fast_division_is_exact(c) in (True, False)
+
+
 def test_backproject_cube64_golden(be, oracle, golden_dir):
     gold = np.load(os.path.join(golden_dir, "cube64.npz"))
     g = (64, 64, 0.2, 0.2, 0, 0, 100, 200, 45.0)
