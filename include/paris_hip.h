@@ -208,13 +208,18 @@ int paris_hip_last_backproject_ms(paris_hip_ctx* ctx, float* ms);
  * still in the ring, oldest first. Default capacity is 1 (paris_hip_last_backproject_ms). */
 int paris_hip_backproject_timing_arm(paris_hip_ctx* ctx, uint32_t capacity);
 int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* ms, uint32_t max_n, uint32_t* n_out);
-/* Selects the backprojection kernel variant: 0 = default (LDS-staged), 1 = reference-order gather kernel
- * without LDS (slow, for cross-checking). */
+/* Selects the backprojection kernel: 0 = default (slice kernel when the volume is 16-byte aligned with dim_x % 4
+ * == 0 and no narrower lane width was requested, else the tile kernel), 1 = one-thread-per-voxel gather kernel
+ * without LDS (slow, for cross-checking), 2 = tile kernel (z-walk per workgroup), 3 = slice kernel (one slice per
+ * wave; falls back to 2 when the alignment does not allow it). All give identical bits. */
 int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant);
 /* Tuning knobs of the LDS-staged kernel; 0 keeps the default. vx: voxels per lane along x (1, 2, 4; capped by
  * the volume's alignment), unroll: z slices in flight per lane (1, 2, 4), tz: slices per tile, lds_bytes: LDS
  * budget per workgroup for the staged detector box (1024..65536). Results do not depend on any of them. */
 int paris_hip_set_backproject_tuning(paris_hip_ctx* ctx, int vx, int unroll, int tz, int lds_bytes);
+/* Shape of the slice kernel: waves (= slices per tile) x row groups per lane; (16,4) (16,2) (8,4) (8,2) (8,1),
+ * (0,0) = default. */
+int paris_hip_set_backproject_slice_shape(paris_hip_ctx* ctx, int waves, int row_groups);
 /* Workgroup -> tile order (-1 default, 0 x-fastest, 1 z-fastest, 5 one contiguous band per XCD) and the cache
  * policy of the volume stream (1 nontemporal, 0 default, -1 library default). Performance only. */
 int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, int nontemporal);

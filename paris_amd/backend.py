@@ -251,6 +251,10 @@ class Backend:
         check(self._L.paris_hip_set_backproject_fast_division(self._ctx, int(bool(enable))),
               "paris_hip_set_backproject_fast_division")
 
+    def set_backproject_slice_shape(self, waves=0, row_groups=0):
+        check(self._L.paris_hip_set_backproject_slice_shape(self._ctx, waves, row_groups),
+              "paris_hip_set_backproject_slice_shape")
+
     def set_backproject_tuning(self, vx=0, unroll=0, tz=0, lds_bytes=0):
         check(self._L.paris_hip_set_backproject_tuning(self._ctx, vx, unroll, tz, lds_bytes),
               "paris_hip_set_backproject_tuning")

@@ -187,7 +187,159 @@ namespace
     }
 
     // --------------------------------------------------------------------------------------------
-    // Tile kernel. 1-D grid over ntx * nty * ntz tiles of 64 x TY x g.tz voxels, TY = 4*VX.
+    // Pieces shared by the two LDS-staged kernels
+    // --------------------------------------------------------------------------------------------
+
+    // the staged detector box of one tile (workgroup-uniform)
+    struct Box
+    {
+        int bx0, by0; // first staged detector column / row
+        int bw;       // staged columns (0: nothing staged)
+        int bhs;      // staged rows
+        int stride;   // LDS row stride in floats (odd)
+    };
+
+    // Detector bounding box of the voxel tile [k0,k1] x [l0,l1] x [m0,m1]. h is a projective function of (x,y) and
+    // v of (z, factor), so the extremes sit on tile corners; the four corners are evaluated by four lanes in
+    // parallel and min/max-reduced with two butterfly shuffles (every wave computes the same box). The box is
+    // widened by the taps' reach plus one pixel of rounding slack, clipped to the detector and cut to the LDS
+    // budget; a tap that still falls outside is served from global memory, so this only has to be right for speed.
+    __device__ __forceinline__ Box tile_box(const BpParams& g, uint32_t k0, uint32_t k1, uint32_t l0, uint32_t l1,
+                                            uint32_t m0, uint32_t m1, uint32_t lane, uint32_t box_floats)
+    {
+        const uint32_t ci = lane & 3u;
+        const ColConst c = column_constants(g, g.k_off + ((ci & 1u) ? k1 : k0), g.l_off + ((ci & 2u) ? l1 : l0));
+        float hmin = c.h, hmax = c.h, fmin = c.factor, fmax = c.factor;
+#pragma unroll
+        for(int m = 1; m <= 2; m <<= 1)
+        {
+            hmin = fminf(hmin, __shfl_xor(hmin, m));
+            hmax = fmaxf(hmax, __shfl_xor(hmax, m));
+            fmin = fminf(fmin, __shfl_xor(fmin, m));
+            fmax = fmaxf(fmax, __shfl_xor(fmax, m));
+        }
+        const float z_c = g.z_base + static_cast<float>(g.m_off + ((ci & 1u) ? m1 : m0)) * g.l_vx_z;
+        const float v_c = v_coordinate<false>(g, z_c, (ci & 2u) ? fmax : fmin);
+        float vmin = v_c, vmax = v_c;
+#pragma unroll
+        for(int m = 1; m <= 2; m <<= 1)
+        {
+            vmin = fminf(vmin, __shfl_xor(vmin, m));
+            vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+        }
+        // identical in every lane by construction; readfirstlane moves them to scalar registers
+        const int ihmin = __builtin_amdgcn_readfirstlane(to_int_clamped(hmin));
+        const int ihmax = __builtin_amdgcn_readfirstlane(to_int_clamped(hmax));
+        const int ivmin = __builtin_amdgcn_readfirstlane(to_int_clamped(vmin));
+        const int ivmax = __builtin_amdgcn_readfirstlane(to_int_clamped(vmax));
+
+        Box b;
+        b.bx0 = max(ihmin - 1, 0);
+        b.by0 = max(ivmin - 1, 0);
+        const int bx1 = min(ihmax + 2, static_cast<int>(g.p_dim_x) - 1);
+        const int by1 = min(ivmax + 2, static_cast<int>(g.p_dim_y) - 1);
+        b.bw = bx1 - b.bx0 + 1;
+        int bh = by1 - b.by0 + 1;
+        if(b.bw < 2 || bh < 2)
+        {
+            b.bw = 0;
+            bh = 0;
+        }
+        b.stride = b.bw | 1;
+        b.bhs = min(bh, static_cast<int>(box_floats) / b.stride); // rows that fit the LDS budget
+        if(b.bhs < 2)
+        {
+            // nothing useful fits: stage nothing, every valid tap takes the global path
+            b.bw = 0;
+            b.bhs = 0;
+            b.stride = 1;
+        }
+        return b;
+    }
+
+    // global -> LDS: one wave per detector row, lanes along the row (coalesced)
+    __device__ __forceinline__ void stage_box(const BpParams& g, const Box& b, float* lds_box, uint32_t wave,
+                                              uint32_t n_waves, uint32_t lane)
+    {
+        for(int r = static_cast<int>(wave); r < b.bhs; r += static_cast<int>(n_waves))
+        {
+            const float* src = g.proj + static_cast<size_t>(b.by0 + r) * g.p_pitch + b.bx0;
+            float* dst = lds_box + r * b.stride;
+            for(int c = static_cast<int>(lane); c < b.bw; c += 64)
+                dst[c] = src[c];
+        }
+    }
+
+    // z-invariant state of one (x,y) voxel column
+    struct Column
+    {
+        float factor, u;
+        float wx1, wx2; // x interpolation weights
+        float ymax;     // p_dim_y, or -inf when the column's x taps are outside the detector
+        int xoff;       // LDS column of the left tap, or -1 when it is not inside the staged box
+        int x1i;        // detector column of the left tap (global-memory path)
+    };
+
+    __device__ __forceinline__ Column make_column(const BpParams& g, const Box& b, uint32_t K, uint32_t L)
+    {
+        const ColConst c = column_constants(g, K, L);
+        const float x1 = floorf(c.h); // :55-58
+        const float x2 = x1 + 1.f;
+        const bool x_valid = (x1 >= 0.f) && (x2 < g.p_dim_x_f); // :65-66
+        Column col;
+        col.factor = c.factor;
+        col.u = c.u;
+        // :77-78 divide by (x2 - x1), which is exactly 1.f whenever x_valid (|x1| < 2^24): the divisions are the
+        // identity and are dropped; for an invalid column the weights are never used
+        col.wx2 = x2 - c.h;
+        col.wx1 = c.h - x1;
+        col.ymax = x_valid ? g.p_dim_y_f : -INFINITY; // folds the x validity into the y2 test
+        col.x1i = static_cast<int>(x1);
+        const int rel = col.x1i - b.bx0;
+        col.xoff = (x_valid && rel >= 0 && rel <= b.bw - 2) ? rel : -1;
+        return col;
+    }
+
+    // one voxel-update: src/openmp/backprojection.cpp:130-140 for slice coordinate z_m of column col
+    template <bool FD>
+    __device__ __forceinline__ float voxel_contribution(const BpParams& g, const Box& b, const float* lds_box, float z_m,
+                                                        const Column& col)
+    {
+        const float v = v_coordinate<FD>(g, z_m, col.factor);
+        const float y1 = floorf(v);
+        const float y2 = y1 + 1.f;
+        const bool valid = (y1 >= 0.f) && (y2 < col.ymax); // :67-68 (+ x validity)
+        const int y1i = static_cast<int>(y1);
+        const int rrel = y1i - b.by0;
+        const int bhs_m2 = b.bhs - 2;
+        const bool inbox = col.xoff >= 0 && rrel >= 0 && rrel <= bhs_m2;
+        const int rc = min(max(rrel, 0), max(bhs_m2, 0));
+        const int base = rc * b.stride + max(col.xoff, 0);
+        float q11 = lds_box[base];
+        float q21 = lds_box[base + 1];
+        float q12 = lds_box[base + b.stride];
+        float q22 = lds_box[base + b.stride + 1];
+        if(valid && !inbox)
+        {
+            // tap outside the staged box: read the detector directly (valid => in bounds). volatile keeps the
+            // compiler from merging these loads with the LDS reads into flat loads of a selected pointer
+            const volatile float* pr = g.proj + static_cast<size_t>(y1i) * g.p_pitch + col.x1i;
+            q11 = pr[0];
+            q21 = pr[1];
+            q12 = pr[g.p_pitch];
+            q22 = pr[g.p_pitch + 1];
+        }
+        const float interp_y1 = col.wx2 * q11 + col.wx1 * q21; // :77
+        const float interp_y2 = col.wx2 * q12 + col.wx1 * q22; // :78
+        // :80 divides by (y2 - y1) == 1.f exactly whenever valid -- dropped, as above
+        float det = (y2 - v) * interp_y1 + (v - y1) * interp_y2;
+        det = valid ? det : 0.f;         // :71
+        return 0.5f * det * col.u * col.u; // :140
+    }
+
+    // --------------------------------------------------------------------------------------------
+    // Tile kernel (z-walk in time). 1-D grid over ntx * nty * ntz tiles of 64 x TY x g.tz voxels, TY = 4*VX.
+    // Serves every alignment (VX = 1, 2, 4).
     // --------------------------------------------------------------------------------------------
     template <int VX, int UNROLL, bool NT, bool FD>
     __global__ void __launch_bounds__(256) bp_tile_kernel(const BpParams g)
@@ -212,56 +364,8 @@ namespace
         const uint32_t l1 = min(l0 + TY - 1u, g.v_dim_y - 1u);
         const uint32_t m1 = min(m0 + g.tz - 1u, g.v_dim_z - 1u);
 
-        // ---- detector bounding box of the tile (uniform) ------------------------------------
-        // h is a projective function of (x,y) and v of (z, factor): extremes sit on tile corners.
-        float hmin = INFINITY, hmax = -INFINITY, fmin = INFINITY, fmax = -INFINITY;
-#pragma unroll
-        for(int ci = 0; ci < 4; ++ci)
-        {
-            const ColConst c = column_constants(g, g.k_off + ((ci & 1) ? k1 : k0), g.l_off + ((ci & 2) ? l1 : l0));
-            hmin = fminf(hmin, c.h);
-            hmax = fmaxf(hmax, c.h);
-            fmin = fminf(fmin, c.factor);
-            fmax = fmaxf(fmax, c.factor);
-        }
-        const float z_lo = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
-        const float z_hi = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
-        const float v00 = v_coordinate<false>(g, z_lo, fmin), v01 = v_coordinate<false>(g, z_lo, fmax);
-        const float v10 = v_coordinate<false>(g, z_hi, fmin), v11 = v_coordinate<false>(g, z_hi, fmax);
-        const float vmin = fminf(fminf(v00, v01), fminf(v10, v11));
-        const float vmax = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
-
-        const int bx0 = max(to_int_clamped(hmin) - 1, 0);
-        const int bx1 = min(to_int_clamped(hmax) + 2, static_cast<int>(g.p_dim_x) - 1);
-        const int by0 = max(to_int_clamped(vmin) - 1, 0);
-        const int by1 = min(to_int_clamped(vmax) + 2, static_cast<int>(g.p_dim_y) - 1);
-        int bw = bx1 - bx0 + 1;
-        int bh = by1 - by0 + 1;
-        if(bw < 2 || bh < 2)
-        {
-            bw = 0;
-            bh = 0;
-        }
-        int stride = bw | 1;
-        int bhs = min(bh, static_cast<int>(g.lds_floats) / stride); // rows that fit the LDS budget
-        if(bhs < 2)
-        {
-            // nothing useful fits: stage nothing, every valid tap takes the global path
-            bw = 0;
-            bhs = 0;
-            stride = 1;
-        }
-        const int bw_m2 = bw - 2;
-        const int bhs_m2 = bhs - 2;
-
-        // ---- stage the box: one wave per detector row, lanes along the row ---------------------
-        for(int r = static_cast<int>(wave); r < bhs; r += 4)
-        {
-            const float* src = g.proj + static_cast<size_t>(by0 + r) * g.p_pitch + bx0;
-            float* dst = lds + r * stride;
-            for(int c = static_cast<int>(lane); c < bw; c += 64)
-                dst[c] = src[c];
-        }
+        const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats);
+        stage_box(g, box, lds, wave, 4u, lane);
         __syncthreads();
 
         // ---- per-lane columns --------------------------------------------------------------------
@@ -272,28 +376,10 @@ namespace
         if(k >= g.v_dim_x || l >= g.v_dim_y)
             return;
 
-        float factor[VX], u[VX], wx1[VX], wx2[VX], ymax[VX];
-        int xoff[VX], x1i[VX];
-        bool colin[VX];
+        Column col[VX];
 #pragma unroll
         for(int j = 0; j < VX; ++j)
-        {
-            const ColConst c = column_constants(g, g.k_off + k + j, g.l_off + l);
-            const float x1 = floorf(c.h); // :55-58
-            const float x2 = x1 + 1.f;
-            const bool x_valid = (x1 >= 0.f) && (x2 < g.p_dim_x_f); // :65-66
-            factor[j] = c.factor;
-            u[j] = c.u;
-            // :77-78 divide by (x2 - x1), which is exactly 1.f whenever x_valid (|x1| < 2^24): the divisions
-            // are the identity and are dropped; for an invalid column the weights are never used
-            wx2[j] = x2 - c.h;
-            wx1[j] = c.h - x1;
-            ymax[j] = x_valid ? g.p_dim_y_f : -INFINITY; // folds the x validity into the y2 test
-            x1i[j] = static_cast<int>(x1);
-            const int rel = x1i[j] - bx0;
-            colin[j] = x_valid && rel >= 0 && rel <= bw_m2;
-            xoff[j] = min(max(rel, 0), max(bw_m2, 0));
-        }
+            col[j] = make_column(g, box, g.k_off + k + j, g.l_off + l);
 
         using vec_t = typename vec_of<VX>::type;
         const size_t slice = static_cast<size_t>(g.v_dim_x) * g.v_dim_y;
@@ -304,37 +390,7 @@ namespace
             const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + m_local) * g.l_vx_z; // :118
 #pragma unroll
             for(int j = 0; j < VX; ++j)
-            {
-                const float v = v_coordinate<FD>(g, z_m, factor[j]);
-                const float y1 = floorf(v);
-                const float y2 = y1 + 1.f;
-                const bool valid = (y1 >= 0.f) && (y2 < ymax[j]); // :67-68 (+ x validity)
-                const int y1i = static_cast<int>(y1);
-                const int rrel = y1i - by0;
-                const bool inbox = colin[j] && rrel >= 0 && rrel <= bhs_m2;
-                const int rc = min(max(rrel, 0), max(bhs_m2, 0));
-                const int base = rc * stride + xoff[j];
-                float q11 = lds[base];
-                float q21 = lds[base + 1];
-                float q12 = lds[base + stride];
-                float q22 = lds[base + stride + 1];
-                if(valid && !inbox)
-                {
-                    // tap outside the staged box: read the detector directly (valid => in bounds). volatile keeps
-                    // the compiler from merging these loads with the LDS reads into flat loads of a selected pointer
-                    const volatile float* pr = g.proj + static_cast<size_t>(y1i) * g.p_pitch + x1i[j];
-                    q11 = pr[0];
-                    q21 = pr[1];
-                    q12 = pr[g.p_pitch];
-                    q22 = pr[g.p_pitch + 1];
-                }
-                const float interp_y1 = wx2[j] * q11 + wx1[j] * q21; // :77
-                const float interp_y2 = wx2[j] * q12 + wx1[j] * q22; // :78
-                // :80 divides by (y2 - y1) == 1.f exactly whenever valid -- dropped, as above
-                float det = (y2 - v) * interp_y1 + (v - y1) * interp_y2;
-                det = valid ? det : 0.f; // :71
-                elem<VX>(acc, j) += 0.5f * det * u[j] * u[j];                                    // :140
-            }
+                elem<VX>(acc, j) += voxel_contribution<FD>(g, box, lds, z_m, col[j]);
         };
 
         uint32_t mm = 0;
@@ -357,6 +413,101 @@ namespace
             update(acc, mm);
             store_voxels<VX, NT>(vp + mm * slice, acc);
         }
+    }
+
+    // --------------------------------------------------------------------------------------------
+    // Slice kernel (z across waves). A workgroup of NW waves owns a tile of 64 x (4*RPL) columns x NW slices; wave w
+    // updates slice w, so a thread issues its RPL 16-byte loads once, updates 4*RPL voxels and stores: the volume
+    // stream has the shape of the fastest plain sweep (tools/membench6.hip: 6.0 TB/s against 5.5 for the z-walk).
+    // The z-invariant column state that the tile kernel keeps in registers is computed once per workgroup (one
+    // thread per column) and shared through LDS as structure-of-arrays, read back as float4 per 4 columns.
+    // Needs dim_x % 4 == 0 and a 16-byte aligned volume. LDS: 7 * 64 * 4*RPL floats of column state + the box.
+    // --------------------------------------------------------------------------------------------
+    template <int NW, int RPL, bool NT, bool FD>
+    __global__ void __launch_bounds__(NW * 64, 8) bp_slice_kernel(const BpParams g)
+    {
+        extern __shared__ __attribute__((aligned(16))) float lds[];
+        constexpr uint32_t TY = 4u * RPL;
+        constexpr uint32_t NCOL = 64u * TY;
+        float* c_factor = lds;
+        float* c_u = lds + NCOL;
+        float* c_wx1 = lds + 2u * NCOL;
+        float* c_wx2 = lds + 3u * NCOL;
+        float* c_ymax = lds + 4u * NCOL;
+        int* c_xoff = reinterpret_cast<int*>(lds + 5u * NCOL);
+        int* c_x1i = reinterpret_cast<int*>(lds + 6u * NCOL);
+        float* lds_box = lds + 7u * NCOL;
+
+        const uint32_t tid = threadIdx.x;
+        const uint32_t lane = tid & 63u;
+        const uint32_t wave = tid >> 6;
+
+        uint32_t bx, by, bz;
+        if(!tile_of_block(g, blockIdx.x, bx, by, bz))
+            return;
+        const uint32_t k0 = bx * 64u;
+        const uint32_t l0 = by * TY;
+        const uint32_t m0 = bz * NW;
+        const uint32_t k1 = min(k0 + 63u, g.v_dim_x - 1u);
+        const uint32_t l1 = min(l0 + TY - 1u, g.v_dim_y - 1u);
+        const uint32_t m1 = min(m0 + NW - 1u, g.v_dim_z - 1u);
+
+        const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats - 7u * NCOL);
+        stage_box(g, box, lds_box, wave, NW, lane);
+
+        // column state: thread t computes columns t, t + NW*64, ...; column c = cy * 64 + cx
+        for(uint32_t c = tid; c < NCOL; c += NW * 64u)
+        {
+            const uint32_t cx = c & 63u, cy = c >> 6;
+            const Column col = make_column(g, box, g.k_off + min(k0 + cx, k1), g.l_off + min(l0 + cy, l1));
+            c_factor[c] = col.factor;
+            c_u[c] = col.u;
+            c_wx1[c] = col.wx1;
+            c_wx2[c] = col.wx2;
+            c_ymax[c] = col.ymax;
+            c_xoff[c] = col.xoff;
+            c_x1i[c] = col.x1i;
+        }
+        __syncthreads();
+
+        const uint32_t m = m0 + wave;
+        if(m > m1)
+            return;
+        const uint32_t xq = lane & 15u, yy = lane >> 4;
+        const uint32_t k = k0 + xq * 4u;
+        if(k >= g.v_dim_x)
+            return;
+        const float z_m = g.z_base + static_cast<float>(g.m_off + m) * g.l_vx_z; // :118
+        float* vp = g.vol + (static_cast<size_t>(m) * g.v_dim_y + l0 + yy) * g.v_dim_x + k;
+        const size_t row4 = static_cast<size_t>(4u) * g.v_dim_x;
+
+        float4 acc[RPL];
+#pragma unroll
+        for(int r = 0; r < RPL; ++r)
+            if(l0 + yy + 4u * r < g.v_dim_y)
+                acc[r] = load_voxels<4, NT>(vp + r * row4);
+#pragma unroll
+        for(int r = 0; r < RPL; ++r)
+        {
+            if(l0 + yy + 4u * r >= g.v_dim_y)
+                continue;
+            const uint32_t c = (yy + 4u * r) * 64u + xq * 4u;
+            const float4 f4 = *reinterpret_cast<const float4*>(c_factor + c);
+            const float4 u4 = *reinterpret_cast<const float4*>(c_u + c);
+            const float4 a4 = *reinterpret_cast<const float4*>(c_wx1 + c);
+            const float4 b4 = *reinterpret_cast<const float4*>(c_wx2 + c);
+            const float4 y4 = *reinterpret_cast<const float4*>(c_ymax + c);
+            const int4 o4 = *reinterpret_cast<const int4*>(c_xoff + c);
+            const int4 i4 = *reinterpret_cast<const int4*>(c_x1i + c);
+            acc[r].x += voxel_contribution<FD>(g, box, lds_box, z_m, Column{f4.x, u4.x, a4.x, b4.x, y4.x, o4.x, i4.x});
+            acc[r].y += voxel_contribution<FD>(g, box, lds_box, z_m, Column{f4.y, u4.y, a4.y, b4.y, y4.y, o4.y, i4.y});
+            acc[r].z += voxel_contribution<FD>(g, box, lds_box, z_m, Column{f4.z, u4.z, a4.z, b4.z, y4.z, o4.z, i4.z});
+            acc[r].w += voxel_contribution<FD>(g, box, lds_box, z_m, Column{f4.w, u4.w, a4.w, b4.w, y4.w, o4.w, i4.w});
+        }
+#pragma unroll
+        for(int r = 0; r < RPL; ++r)
+            if(l0 + yy + 4u * r < g.v_dim_y)
+                store_voxels<4, NT>(vp + r * row4, acc[r]);
     }
 
     // --------------------------------------------------------------------------------------------
@@ -442,6 +593,58 @@ namespace
             launch_tile_unroll<VX, false, true>(g, unroll, stream);
         else
             launch_tile_unroll<VX, false, false>(g, unroll, stream);
+    }
+
+    // ---- slice kernel launchers ------------------------------------------------------------------------------
+    template <int NW, int RPL, bool NT, bool FD>
+    int launch_slice(BpParams& g, uint32_t box_bytes, hipStream_t stream)
+    {
+        constexpr uint32_t TY = 4u * RPL;
+        constexpr uint32_t state_floats = 7u * 64u * TY;
+        g.tz = NW;
+        g.lds_floats = state_floats + box_bytes / sizeof(float);
+        g.ntx = (g.v_dim_x + 63u) / 64u;
+        g.nty = (g.v_dim_y + TY - 1u) / TY;
+        g.ntz = (g.v_dim_z + NW - 1u) / NW;
+        uint32_t blocks = g.ntx * g.nty * g.ntz;
+        if(g.order == 5u)
+            blocks = ((blocks + 7u) / 8u) * 8u;
+        const uint32_t lds_bytes = g.lds_floats * sizeof(float);
+        if(lds_bytes > 64u * 1024u)
+        {
+            static thread_local bool raised = false; // per host thread == per device (one ctx per thread)
+            if(!raised)
+            {
+                PARIS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bp_slice_kernel<NW, RPL, NT, FD>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL((bp_slice_kernel<NW, RPL, NT, FD>), dim3(blocks), dim3(NW * 64), lds_bytes, stream, g);
+        return PARIS_HIP_SUCCESS;
+    }
+
+    template <int NW, int RPL>
+    int launch_slice_flags(BpParams& g, uint32_t box_bytes, bool nt, bool fd, hipStream_t stream)
+    {
+        if(nt && fd)
+            return launch_slice<NW, RPL, true, true>(g, box_bytes, stream);
+        if(nt)
+            return launch_slice<NW, RPL, true, false>(g, box_bytes, stream);
+        if(fd)
+            return launch_slice<NW, RPL, false, true>(g, box_bytes, stream);
+        return launch_slice<NW, RPL, false, false>(g, box_bytes, stream);
+    }
+
+    // shape = (waves = slices per tile, row groups per lane); supported: 16x4 16x2 8x4 8x2 8x1
+    int launch_slice_shape(BpParams& g, int nw, int rpl, uint32_t box_bytes, bool nt, bool fd, hipStream_t stream)
+    {
+        if(nw == 16 && rpl == 4) return launch_slice_flags<16, 4>(g, box_bytes, nt, fd, stream);
+        if(nw == 16 && rpl == 2) return launch_slice_flags<16, 2>(g, box_bytes, nt, fd, stream);
+        if(nw == 8 && rpl == 4) return launch_slice_flags<8, 4>(g, box_bytes, nt, fd, stream);
+        if(nw == 8 && rpl == 2) return launch_slice_flags<8, 2>(g, box_bytes, nt, fd, stream);
+        if(nw == 8 && rpl == 1) return launch_slice_flags<8, 1>(g, box_bytes, nt, fd, stream);
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     }
 
     // Is div_by_constant exact for this divisor? Checked once per ctx and divisor on the GPU (about 2 ms).
@@ -553,7 +756,16 @@ extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_
             vx = ctx->bp_vx;
         const int unroll = ctx->bp_unroll ? ctx->bp_unroll : 2;
         const bool nt = ctx->bp_nt != 0;
-        if(vx == 4)
+        const bool want_slice = ctx->bp_variant == 3 || (ctx->bp_variant == 0 && ctx->bp_vx == 0);
+        if(want_slice && vx == 4)
+        {
+            const int nw = ctx->bp_slice_nw ? ctx->bp_slice_nw : 16;
+            const int rpl = ctx->bp_slice_rpl ? ctx->bp_slice_rpl : 4;
+            const uint32_t box_bytes = ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT;
+            if(int rc = launch_slice_shape(g, nw, rpl, box_bytes, nt, fd, ctx->stream))
+                return rc;
+        }
+        else if(vx == 4)
             launch_tile_flags<4>(g, unroll, nt, fd, ctx->stream);
         else if(vx == 2)
             launch_tile_flags<2>(g, unroll, nt, fd, ctx->stream);
@@ -609,7 +821,7 @@ extern "C" int paris_hip_last_backproject_ms(paris_hip_ctx* ctx, float* ms)
 
 extern "C" int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant)
 {
-    if(ctx == nullptr || variant < 0 || variant > 1)
+    if(ctx == nullptr || variant < 0 || variant > 3)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_variant = variant;
     return PARIS_HIP_SUCCESS;
@@ -642,6 +854,19 @@ extern "C" int paris_hip_set_backproject_fast_division(paris_hip_ctx* ctx, int e
     if(ctx == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_fastdiv = enable ? 1 : 0;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_set_backproject_slice_shape(paris_hip_ctx* ctx, int waves, int row_groups)
+{
+    if(ctx == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    const bool ok = (waves == 0 && row_groups == 0) || (waves == 16 && (row_groups == 4 || row_groups == 2))
+                    || (waves == 8 && (row_groups == 4 || row_groups == 2 || row_groups == 1));
+    if(!ok)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    ctx->bp_slice_nw = waves;
+    ctx->bp_slice_rpl = row_groups;
     return PARIS_HIP_SUCCESS;
 }
 

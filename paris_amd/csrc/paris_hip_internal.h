@@ -42,6 +42,7 @@ struct paris_hip_ctx
     int bp_vx = 0, bp_unroll = 0; // 0 = automatic
     uint32_t bp_tz = 0, bp_lds_bytes = 0;
     int bp_order = -1; // -1 = default mapping
+    int bp_slice_nw = 0, bp_slice_rpl = 0; // slice kernel shape, 0 = default
     int bp_nt = 1;     // nontemporal volume loads/stores
     int bp_fastdiv = 1; // use the validated multiply+2 FMA division by the pixel pitch when it is exact
     std::map<uint32_t, bool> fastdiv_exact; // divisor bits -> exhaustive check result

@@ -192,7 +192,7 @@ def assert_bit_equal(got, want):
             len(bad), got.size, x, y, z, got[z, y, x], want[z, y, x]))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_backproject_kat_full_bit_exact(be, oracle, kat_golden, variant):
     det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
     vg = B.calculate_volume_geometry(det)
@@ -237,11 +237,13 @@ def test_backproject_every_kernel_shape_bit_exact(be, oracle, tuning):
     ovg = oracle.VolumeGeometry(72, 40, 45, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
     projs = [oracle.lcg_projection(96, 80, i) - np.float32(0.5) for i in range(9)]
     want = oracle_backproject_all(oracle, projs, odet, ovg, (45, 40, 72))
+    be.set_backproject_variant(2)
     be.set_backproject_tuning(**tuning)
     try:
         got = hip_backproject_all(be, projs, det, vg, (45, 40, 72))
     finally:
         be.set_backproject_tuning()
+        be.set_backproject_variant(0)
     assert_bit_equal(got, want)
 
 
@@ -269,6 +271,34 @@ def test_fast_division_exhaustive_check(be):
     # odd divisors: the answer may be either, it just has to come back
     for c in (float(np.float32(1.0) - np.float32(2.0 ** -24)), 1e-38, 3e38, 1e-42):
         assert be.fast_division_is_exact(c) in (True, False)
+
+
+@pytest.mark.parametrize("shape", [(16, 4), (16, 2), (8, 4), (8, 2), (8, 1)])
+@pytest.mark.parametrize("lds_bytes", [0, 1024])
+def test_backproject_slice_kernel_shapes_bit_exact(be, oracle, shape, lds_bytes):
+    """The slice kernel (one slice per wave, column state shared through LDS) in every shape, on a volume whose
+    dims leave partial tiles in x, y and z; lds_bytes = 1024 forces the global-memory tap path."""
+    g = (96, 80, 0.2, 0.25, -2.5, 1.25, 150, 250, 40.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    dims = (45, 42, 72)  # z, y, x: 72 = 64 + 8, 42 rows, 45 slices
+    vg = B.VolumeGeometry(dims[2], dims[1], dims[0], nat.l_vx_x * 1.3, nat.l_vx_x * 2.0, nat.l_vx_x * 1.7)
+    ovg = oracle.VolumeGeometry(dims[2], dims[1], dims[0], vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    projs = [oracle.lcg_projection(96, 80, i) - np.float32(0.5) for i in range(5)]
+    want = oracle_backproject_all(oracle, projs, odet, ovg, dims)
+    be.set_backproject_variant(3)
+    be.set_backproject_slice_shape(*shape)
+    be.set_backproject_tuning(lds_bytes=lds_bytes)
+    try:
+        for order in (0, 1, 5):
+            be.set_backproject_order(order, 1)
+            got = hip_backproject_all(be, projs, det, vg, dims)
+            assert_bit_equal(got, want)
+    finally:
+        be.set_backproject_variant(0)
+        be.set_backproject_slice_shape()
+        be.set_backproject_tuning()
+        be.set_backproject_order()
 
 
 def test_backproject_cube64_golden(be, oracle, golden_dir):

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--angles", default="0,17,45,90,200")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--order", default="0,1,5")
+    ap.add_argument("--slice", default="", help="slice kernel shapes, e.g. 16x4,8x2 (empty: tile kernel)")
     ap.add_argument("--nt", default="0,1")
     args = ap.parse_args()
     n = args.n
@@ -39,6 +40,28 @@ def main():
     angles = [int(a) for a in args.angles.split(",")]
     voxels = float(n) * n * args.slices
     results = []
+    shapes = [tuple(int(x) for x in sh.split("x")) for sh in args.slice.split(",") if sh]
+    for nw, rpl in shapes:
+        be.set_backproject_variant(3)
+        be.set_backproject_slice_shape(nw, rpl)
+        for lds, order, nt in itertools.product(*[[int(x) for x in s.split(",")] for s in (args.lds, args.order, args.nt)]):
+            be.set_backproject_tuning(0, 0, 0, lds)
+            be.set_backproject_order(order, nt)
+            ms = []
+            for rep in range(args.reps + 1):
+                for a in angles:
+                    d_p.idx = a * 4
+                    B.backproject(be, d_p, d_v, z_first, det, vg, False, False, None)
+                    t = be.last_backproject_ms()
+                    if rep > 0:
+                        ms.append(t)
+            avg = sum(ms) / len(ms)
+            r = dict(kernel="slice", nw=nw, rpl=rpl, lds=lds, order=order, nt=nt, ms=avg, ms_min=min(ms), ms_max=max(ms),
+                     gbs=8 * voxels / avg / 1e6, gvox=voxels / avg / 1e6)
+            results.append(r)
+            print(json.dumps(r), flush=True)
+    be.set_backproject_variant(2)
+    be.set_backproject_slice_shape()
     for vx, un, tz, lds, order, nt in itertools.product(*[[int(x) for x in s.split(",")] for s in (args.vx, args.unroll, args.tz, args.lds, args.order, args.nt)]):
         be.set_backproject_tuning(vx, un, tz, lds)
         be.set_backproject_order(order, nt)
