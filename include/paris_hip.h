@@ -159,6 +159,19 @@ int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, 
                           const paris_region_of_interest* roi, float sin_phi, float cos_phi, float delta_s,
                           float delta_t);
 
+/* Extension (no reference counterpart; BASELINE config 5 "fp16-in / fp32-accum"): the filtered projection is stored
+ * as IEEE half (p_pitch in bytes, >= 2*p_dim_x); pixels are widened to fp32 exactly when they are staged and every
+ * operation afterwards is the fp32 one of paris_hip_backproject, so the result equals paris_hip_backproject on the
+ * half-rounded projection, bit for bit. paris_hip_convert_projection_f16 rounds to nearest even. */
+int paris_hip_convert_projection_f16(paris_hip_ctx* ctx, const float* d_src, size_t src_pitch, uint16_t* d_dst,
+                                     size_t dst_pitch, uint32_t dim_x, uint32_t dim_y);
+int paris_hip_backproject_f16(paris_hip_ctx* ctx, const uint16_t* d_p, size_t p_pitch, uint32_t p_dim_x,
+                              uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z,
+                              uint32_t v_offset, const paris_detector_geometry* det_geo,
+                              const paris_volume_geometry* vol_geo, int enable_roi,
+                              const paris_region_of_interest* roi, float sin_phi, float cos_phi, float delta_s,
+                              float delta_t);
+
 /* Extension (no reference counterpart): backprojects n_proj projections in one launch; projection i is at
  * d_p + i * p_stride_bytes. The per-voxel sum is accumulated in projection order, so the result is
  * bit-identical to n_proj successive paris_hip_backproject calls while the volume is read and written
@@ -208,10 +221,9 @@ int paris_hip_last_backproject_ms(paris_hip_ctx* ctx, float* ms);
  * still in the ring, oldest first. Default capacity is 1 (paris_hip_last_backproject_ms). */
 int paris_hip_backproject_timing_arm(paris_hip_ctx* ctx, uint32_t capacity);
 int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* ms, uint32_t max_n, uint32_t* n_out);
-/* Selects the backprojection kernel: 0 = default (slice kernel when the volume is 16-byte aligned with dim_x % 4
- * == 0 and no narrower lane width was requested, else the tile kernel), 1 = one-thread-per-voxel gather kernel
+/* Selects the backprojection kernel: 0 = default (currently the tile kernel), 1 = one-thread-per-voxel gather kernel
  * without LDS (slow, for cross-checking), 2 = tile kernel (z-walk per workgroup), 3 = slice kernel (one slice per
- * wave; falls back to 2 when the alignment does not allow it). All give identical bits. */
+ * wave; needs a 16-byte aligned volume with dim_x % 4 == 0, else falls back to 2). All give identical bits. */
 int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant);
 /* Tuning knobs of the LDS-staged kernel; 0 keeps the default. vx: voxels per lane along x (1, 2, 4; capped by
  * the volume's alignment), unroll: z slices in flight per lane (1, 2, 4), tz: slices per tile, lds_bytes: LDS

@@ -79,6 +79,10 @@ SIGNATURES = {
     "paris_hip_backproject": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _u32, _u32, _u32, _u32,
                                         _P(DetectorGeometry), _P(VolumeGeometry), C.c_int,
                                         _P(RegionOfInterest), _f, _f, _f, _f]),
+    "paris_hip_backproject_f16": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _u32, _u32, _u32, _u32,
+                                            _P(DetectorGeometry), _P(VolumeGeometry), C.c_int,
+                                            _P(RegionOfInterest), _f, _f, _f, _f]),
+    "paris_hip_convert_projection_f16": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u32, _u32]),
     "paris_hip_backproject_batch": (C.c_int, [_vp, _vp, _sz, _sz, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32,
                                               _P(DetectorGeometry), _P(VolumeGeometry), C.c_int,
                                               _P(RegionOfInterest), _P(_f), _P(_f), _f, _f]),

@@ -210,6 +210,27 @@ class Backend:
                                             int(bool(enable_roi)), C.byref(r), sin, cos, delta_s, delta_t),
               "paris_hip_backproject")
 
+    def convert_projection_f16(self, p):
+        """fp32 device projection -> new device buffer of IEEE half pixels (round to nearest even); returns
+        (device address, pitch in bytes). Free with Backend.free(address)."""
+        pitch = (p.dim_x * 2 + 255) // 256 * 256
+        d, dp = C.c_void_p(), C.c_size_t()
+        # the projection allocator hands out rows of `pitch` bytes (pitch / 4 fp32 slots, already a 256 B multiple)
+        check(self._L.paris_hip_malloc_projection(self._ctx, pitch // 4, p.dim_y, C.byref(d), C.byref(dp)),
+              "paris_hip_malloc_projection")
+        self._owned.add(d.value)
+        check(self._L.paris_hip_convert_projection_f16(self._ctx, p.ptr, p.pitch, d.value, dp.value, p.dim_x, p.dim_y),
+              "paris_hip_convert_projection_f16")
+        return d.value, dp.value
+
+    def backproject_f16(self, p_ptr, p_pitch, p_dim_x, p_dim_y, v, v_offset, det_geo, vol_geo, enable_roi, roi, sin, cos,
+                        delta_s, delta_t):
+        r = roi if roi is not None else RegionOfInterest()
+        check(self._L.paris_hip_backproject_f16(self._ctx, p_ptr, p_pitch, p_dim_x, p_dim_y, v.ptr, v.dim_x, v.dim_y,
+                                                v.dim_z, v_offset, C.byref(det_geo), C.byref(vol_geo),
+                                                int(bool(enable_roi)), C.byref(r), sin, cos, delta_s, delta_t),
+              "paris_hip_backproject_f16")
+
     def backproject_batch(self, p_ptr, p_pitch, p_stride, n_proj, p_dim_x, p_dim_y, v, v_offset, det_geo, vol_geo,
                           enable_roi, roi, sins, coss, delta_s, delta_t):
         r = roi if roi is not None else RegionOfInterest()

@@ -25,9 +25,10 @@ namespace
 {
     struct BpParams
     {
-        const float* proj;
+        const void* proj;     // fp32 pixels, or IEEE half pixels when proj_f16 != 0
+        uint32_t proj_f16;
         float* vol;
-        uint32_t p_pitch; // floats per detector row
+        uint32_t p_pitch; // pixels per detector row
         uint32_t p_dim_x, p_dim_y;
         uint32_t v_dim_x, v_dim_y, v_dim_z;
         uint32_t k_off, l_off, m_off; // roi.x1, roi.y1, roi.z1 + v_offset
@@ -257,13 +258,33 @@ namespace
         return b;
     }
 
+    // one detector pixel from global memory as fp32 (half pixels widen exactly); idx in pixels
+    __device__ __forceinline__ float read_pixel(const BpParams& g, size_t idx)
+    {
+        if(g.proj_f16)
+            return static_cast<float>(static_cast<const volatile _Float16*>(g.proj)[idx]);
+        return static_cast<const volatile float*>(g.proj)[idx];
+    }
+
     // global -> LDS: one wave per detector row, lanes along the row (coalesced)
     __device__ __forceinline__ void stage_box(const BpParams& g, const Box& b, float* lds_box, uint32_t wave,
                                               uint32_t n_waves, uint32_t lane)
     {
+        if(g.proj_f16)
+        {
+            // fp16 projection storage (BASELINE config 5): widened to fp32 here, all arithmetic stays fp32
+            for(int r = static_cast<int>(wave); r < b.bhs; r += static_cast<int>(n_waves))
+            {
+                const _Float16* src = static_cast<const _Float16*>(g.proj) + static_cast<size_t>(b.by0 + r) * g.p_pitch + b.bx0;
+                float* dst = lds_box + r * b.stride;
+                for(int c = static_cast<int>(lane); c < b.bw; c += 64)
+                    dst[c] = static_cast<float>(src[c]);
+            }
+            return;
+        }
         for(int r = static_cast<int>(wave); r < b.bhs; r += static_cast<int>(n_waves))
         {
-            const float* src = g.proj + static_cast<size_t>(b.by0 + r) * g.p_pitch + b.bx0;
+            const float* src = static_cast<const float*>(g.proj) + static_cast<size_t>(b.by0 + r) * g.p_pitch + b.bx0;
             float* dst = lds_box + r * b.stride;
             for(int c = static_cast<int>(lane); c < b.bw; c += 64)
                 dst[c] = src[c];
@@ -321,13 +342,13 @@ namespace
         float q22 = lds_box[base + b.stride + 1];
         if(valid && !inbox)
         {
-            // tap outside the staged box: read the detector directly (valid => in bounds). volatile keeps the
-            // compiler from merging these loads with the LDS reads into flat loads of a selected pointer
-            const volatile float* pr = g.proj + static_cast<size_t>(y1i) * g.p_pitch + col.x1i;
-            q11 = pr[0];
-            q21 = pr[1];
-            q12 = pr[g.p_pitch];
-            q22 = pr[g.p_pitch + 1];
+            // tap outside the staged box: read the detector directly (valid => in bounds). The volatile reads in
+            // read_pixel keep the compiler from merging these loads with the LDS reads into flat loads
+            const size_t at = static_cast<size_t>(y1i) * g.p_pitch + col.x1i;
+            q11 = read_pixel(g, at);
+            q21 = read_pixel(g, at + 1);
+            q12 = read_pixel(g, at + g.p_pitch);
+            q22 = read_pixel(g, at + g.p_pitch + 1);
         }
         const float interp_y1 = col.wx2 * q11 + col.wx1 * q21; // :77
         const float interp_y2 = col.wx2 * q12 + col.wx1 * q22; // :78
@@ -529,9 +550,9 @@ namespace
         float interp = 0.f;
         if(x1 >= 0.f && x2 < g.p_dim_x_f && y1 >= 0.f && y2 < g.p_dim_y_f)
         {
-            const float* pr = g.proj + static_cast<size_t>(static_cast<uint32_t>(y1)) * g.p_pitch
-                              + static_cast<uint32_t>(x1);
-            const float q11 = pr[0], q21 = pr[1], q12 = pr[g.p_pitch], q22 = pr[g.p_pitch + 1];
+            const size_t at = static_cast<size_t>(static_cast<uint32_t>(y1)) * g.p_pitch + static_cast<uint32_t>(x1);
+            const float q11 = read_pixel(g, at), q21 = read_pixel(g, at + 1);
+            const float q12 = read_pixel(g, at + g.p_pitch), q22 = read_pixel(g, at + g.p_pitch + 1);
             const float interp_y1 = (x2 - x) / (x2 - x1) * q11 + (x - x1) / (x2 - x1) * q21;
             const float interp_y2 = (x2 - x) / (x2 - x1) * q12 + (x - x1) / (x2 - x1) * q22;
             interp = (y2 - y) / (y2 - y1) * interp_y1 + (y - y1) / (y2 - y1) * interp_y2;
@@ -674,18 +695,18 @@ namespace
     }
 }
 
-extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, uint32_t p_dim_x,
-                                     uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y,
-                                     uint32_t v_dim_z, uint32_t v_offset, const paris_detector_geometry* det_geo,
-                                     const paris_volume_geometry* vol_geo, int enable_roi,
-                                     const paris_region_of_interest* roi, float sin_phi, float cos_phi,
-                                     float delta_s, float delta_t)
+static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, uint32_t p_dim_x,
+                            uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z,
+                            uint32_t v_offset, const paris_detector_geometry* det_geo,
+                            const paris_volume_geometry* vol_geo, int enable_roi, const paris_region_of_interest* roi,
+                            float sin_phi, float cos_phi, float delta_s, float delta_t)
 {
+    const size_t px = f16 ? sizeof(uint16_t) : sizeof(float);
     if(int rc = paris_hip_bind(ctx))
         return rc;
     if(d_p == nullptr || d_v == nullptr || det_geo == nullptr || vol_geo == nullptr || (enable_roi && roi == nullptr))
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    if(p_dim_x == 0 || p_dim_y == 0 || p_pitch < static_cast<size_t>(p_dim_x) * sizeof(float) || p_pitch % sizeof(float) != 0)
+    if(p_dim_x == 0 || p_dim_y == 0 || p_pitch < static_cast<size_t>(p_dim_x) * px || p_pitch % px != 0)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(v_dim_x == 0 || v_dim_y == 0 || v_dim_z == 0)
         return paris_hip_finish(ctx);
@@ -699,8 +720,9 @@ extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_
 
     BpParams g{};
     g.proj = d_p;
+    g.proj_f16 = f16 ? 1u : 0u;
     g.vol = d_v;
-    g.p_pitch = static_cast<uint32_t>(p_pitch / sizeof(float));
+    g.p_pitch = static_cast<uint32_t>(p_pitch / px);
     g.p_dim_x = p_dim_x;
     g.p_dim_y = p_dim_y;
     g.v_dim_x = v_dim_x;
@@ -756,7 +778,7 @@ extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_
             vx = ctx->bp_vx;
         const int unroll = ctx->bp_unroll ? ctx->bp_unroll : 2;
         const bool nt = ctx->bp_nt != 0;
-        const bool want_slice = ctx->bp_variant == 3 || (ctx->bp_variant == 0 && ctx->bp_vx == 0);
+        const bool want_slice = ctx->bp_variant == 3; // measured slower than the tile kernel so far: opt-in only
         if(want_slice && vx == 4)
         {
             const int nw = ctx->bp_slice_nw ? ctx->bp_slice_nw : 16;
@@ -774,6 +796,59 @@ extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_
     }
     PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
     ++ctx->bp_launches;
+    return paris_hip_finish(ctx);
+}
+
+extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, uint32_t p_dim_x,
+                                     uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y,
+                                     uint32_t v_dim_z, uint32_t v_offset, const paris_detector_geometry* det_geo,
+                                     const paris_volume_geometry* vol_geo, int enable_roi,
+                                     const paris_region_of_interest* roi, float sin_phi, float cos_phi,
+                                     float delta_s, float delta_t)
+{
+    return backproject_impl(ctx, d_p, false, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
+                            vol_geo, enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
+}
+
+extern "C" int paris_hip_backproject_f16(paris_hip_ctx* ctx, const uint16_t* d_p, size_t p_pitch, uint32_t p_dim_x,
+                                         uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y,
+                                         uint32_t v_dim_z, uint32_t v_offset, const paris_detector_geometry* det_geo,
+                                         const paris_volume_geometry* vol_geo, int enable_roi,
+                                         const paris_region_of_interest* roi, float sin_phi, float cos_phi,
+                                         float delta_s, float delta_t)
+{
+    return backproject_impl(ctx, d_p, true, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
+                            vol_geo, enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
+}
+
+namespace
+{
+    // fp32 -> IEEE half, round to nearest even (v_cvt_f16_f32), one pixel per thread
+    __global__ void __launch_bounds__(256) to_half_kernel(const float* __restrict__ src, uint32_t src_pitch,
+                                                           _Float16* __restrict__ dst, uint32_t dst_pitch, uint32_t dim_x,
+                                                           uint32_t dim_y)
+    {
+        const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+        if(s >= dim_x)
+            return;
+        for(uint32_t t = blockIdx.y; t < dim_y; t += gridDim.y)
+            dst[static_cast<size_t>(t) * dst_pitch + s] = static_cast<_Float16>(src[static_cast<size_t>(t) * src_pitch + s]);
+    }
+}
+
+extern "C" int paris_hip_convert_projection_f16(paris_hip_ctx* ctx, const float* d_src, size_t src_pitch,
+                                                uint16_t* d_dst, size_t dst_pitch, uint32_t dim_x, uint32_t dim_y)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(d_src == nullptr || d_dst == nullptr || src_pitch % sizeof(float) != 0 || dst_pitch % sizeof(uint16_t) != 0
+       || src_pitch < static_cast<size_t>(dim_x) * sizeof(float) || dst_pitch < static_cast<size_t>(dim_x) * sizeof(uint16_t))
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(dim_x == 0 || dim_y == 0)
+        return paris_hip_finish(ctx);
+    const dim3 grid((dim_x + 255u) / 256u, dim_y < 65535u ? dim_y : 65535u);
+    hipLaunchKernelGGL(to_half_kernel, grid, dim3(256), 0, ctx->stream, d_src, static_cast<uint32_t>(src_pitch / sizeof(float)),
+                       reinterpret_cast<_Float16*>(d_dst), static_cast<uint32_t>(dst_pitch / sizeof(uint16_t)), dim_x, dim_y);
     return paris_hip_finish(ctx);
 }
 

@@ -365,6 +365,84 @@ def test_backproject_batch_equals_sequence(be, oracle, kat_golden):
     be.free(stack)
 
 
+def test_backproject_f16_projections(be, oracle, kat_golden):
+    """BASELINE config 5 storage: projections held as IEEE half, widened when staged, fp32 everywhere else. Equals
+    the oracle fed the half-rounded projection, bit for bit; the conversion kernel rounds like numpy (nearest even)."""
+    det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
+    vg, ovg = B.calculate_volume_geometry(det), oracle.calculate_volume_geometry(odet)
+    rounded = [(kat_golden["filtered"][i] * np.float32(3.0)).astype(np.float16).astype(np.float32) for i in range(8)]
+    want = oracle_backproject_all(oracle, rounded, odet, ovg, (61, 67, 67))
+    for variant in (2, 1):
+        be.set_backproject_variant(variant)
+        d_v = be.make_volume_device(67, 67, 61)
+        for i in range(8):
+            p = kat_golden["filtered"][i] * np.float32(3.0)
+            d_p = to_device(be, p, idx=i)
+            h_ptr, h_pitch = be.convert_projection_f16(d_p)
+            back = np.empty((48, h_pitch // 2), np.float16)
+            _lib.check(_lib.load().paris_hip_memcpy_volume_d2h(be._ctx, back.ctypes.data, h_ptr, h_pitch // 4, 48, 1), "d2h")
+            be.synchronize()
+            assert np.array_equal(back[:, :64].view(np.uint16), p.astype(np.float16).view(np.uint16))
+            s, c = B.stage_angle(det, i)
+            be.backproject_f16(h_ptr, h_pitch, 64, 48, d_v, 0, det, vg, False, None, s, c,
+                               det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
+            be.free(h_ptr)
+            be.free(d_p)
+        got = volume_to_host(be, d_v)
+        be.free(d_v)
+        be.set_backproject_variant(0)
+        assert_bit_equal(got, want)
+
+
+def test_config5_grid_roi_slab_f16(be, oracle):
+    """BASELINE config 5 in miniature on its real grid: 2048^2 detector, 4096^3 voxel grid (half the natural voxel
+    size), ROI {1024..3072}^3, one 2048 x 2048 x 8 slab of the ROI (v_offset inside the ROI), fp16 projections.
+    Crops computed by the oracle through its own ROI + offset path on the half-rounded projection must match."""
+    n = 2048
+    g = (n, n, 0.2, 0.2, 0, 0, 500, 500, 360.0 / 3600)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    l = float(np.float32(nat.l_vx_x) * np.float32(n) / np.float32(4096))
+    vg = B.VolumeGeometry(4096, 4096, 4096, l, l, l)
+    ovg = oracle.VolumeGeometry(4096, 4096, 4096, l, l, l)
+    roi = B.RegionOfInterest(1024, 3072, 1024, 3072, 1024, 3072)
+    rg = B.apply_roi(vg, 1024, 3072, 1024, 3072, 1024, 3072)
+    assert (rg.dim_x, rg.dim_y, rg.dim_z) == (2048, 2048, 2048)
+    v_offset, nz = 1536, 8  # slab 6 of 8 would start at 1536
+    idxs = (5, 1234)
+    projs = [oracle.lcg_projection(n, n, i) - np.float32(0.5) for i in idxs]
+    d_v = be.make_volume_device(2048, 2048, nz)
+    for i, p in zip(idxs, projs):
+        d_p = to_device(be, p, idx=i)
+        h_ptr, h_pitch = be.convert_projection_f16(d_p)
+        s, c = B.stage_angle(det, i)
+        be.backproject_f16(h_ptr, h_pitch, n, n, d_v, v_offset, det, vg, True, roi, s, c, 0.0, 0.0)
+        be.free(h_ptr)
+        be.free(d_p)
+    got = volume_to_host(be, d_v)
+    be.free(d_v)
+    for (x1, y1, z1) in ((0, 0, 0), (1000, 1100, 2), (1984, 1984, 4)):
+        oroi = oracle.RegionOfInterest(1024 + x1, 1024 + x1 + 64, 1024 + y1, 1024 + y1 + 64, 1024, 3072)
+        want = np.zeros((4, 64, 64), np.float32)
+        for i, p in zip(idxs, projs):
+            s, c, ds, dt = oracle.backproject_constants(odet, i)
+            oracle.backproject(want, p.astype(np.float16).astype(np.float32), v_offset + z1, odet, ovg, s, c, ds, dt, oroi)
+        assert_bit_equal(got[z1:z1 + 4, y1:y1 + 64, x1:x1 + 64], want)
+
+
+def test_make_subvolume_information(be):
+    """src/cuda/subvolume_information.cpp:63-118: slab count doubles until volume/devices + 10 projections fit."""
+    det = B.DetectorGeometry(2048, 2048, 0.2, 0.2, 0, 0, 500, 500, 0.25)
+    fits = be.make_subvolume_information(B.VolumeGeometry(2048, 2048, 2048, 0.1, 0.1, 0.1), det, 1)
+    assert (fits.num, fits.geo.dim_z, fits.geo.remainder) == (1, 2048, 0)  # 32 GiB fits one 288 GB device
+    huge = B.VolumeGeometry(8192, 8192, 8191, 0.1, 0.1, 0.1)               # 2 TiB
+    info = be.make_subvolume_information(huge, det, 1)
+    assert info.num >= 8 and info.num & (info.num - 1) == 0
+    assert info.geo.dim_z * info.num + info.geo.remainder == 8191
+    assert (info.geo.dim_x, info.geo.dim_y) == (8192, 8192)
+    assert info.geo.dim_z * 8192 * 8192 * 4 < 288e9
+
+
 # ---- the whole hot path ------------------------------------------------------------------------------------------
 
 def test_pipeline_against_oracle(be, oracle, kat_golden):
