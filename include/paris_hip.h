@@ -97,6 +97,14 @@ int paris_hip_ctx_synchronize(paris_hip_ctx* ctx);
 /* the hipStream_t the ctx enqueues on */
 void* paris_hip_ctx_stream(paris_hip_ctx* ctx);
 
+/* ---- fences (extension): a marker in the ctx stream the host can wait on, so a pipelined driver can reuse a pinned
+ *      upload buffer as soon as the copy that reads it has finished, without draining the whole stream ---------- */
+typedef struct paris_hip_fence paris_hip_fence;
+int paris_hip_fence_create(paris_hip_ctx* ctx, paris_hip_fence** out);
+int paris_hip_fence_record(paris_hip_ctx* ctx, paris_hip_fence* fence);
+int paris_hip_fence_wait(paris_hip_ctx* ctx, paris_hip_fence* fence); /* returns at once if never recorded */
+int paris_hip_fence_destroy(paris_hip_ctx* ctx, paris_hip_fence* fence);
+
 /* ---- memory: make_projection_device / make_volume_device / copy_h2d / copy_d2h
  *      (src/cuda/memory.cpp:33-102, src/openmp/memory.cpp:33-79) ------------------------------------- */
 /* device projection, rows padded to a 256-byte multiple; *pitch receives the row stride in bytes */

@@ -61,6 +61,10 @@ SIGNATURES = {
     "paris_hip_ctx_destroy": (C.c_int, [_vp]),
     "paris_hip_ctx_synchronize": (C.c_int, [_vp]),
     "paris_hip_ctx_stream": (_vp, [_vp]),
+    "paris_hip_fence_create": (C.c_int, [_vp, _P(_vp)]),
+    "paris_hip_fence_record": (C.c_int, [_vp, _vp]),
+    "paris_hip_fence_wait": (C.c_int, [_vp, _vp]),
+    "paris_hip_fence_destroy": (C.c_int, [_vp, _vp]),
     "paris_hip_malloc_projection": (C.c_int, [_vp, _u32, _u32, _P(_vp), _P(_sz)]),
     "paris_hip_malloc_volume": (C.c_int, [_vp, _u32, _u32, _u32, _P(_vp)]),
     "paris_hip_free": (C.c_int, [_vp, _vp]),

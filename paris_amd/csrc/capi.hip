@@ -155,6 +155,66 @@ extern "C" void* paris_hip_ctx_stream(paris_hip_ctx* ctx)
     return ctx ? static_cast<void*>(ctx->stream) : nullptr;
 }
 
+// ---- fences: let a pipelined host loop reuse pinned buffers safely -----------------------------------------
+
+struct paris_hip_fence
+{
+    hipEvent_t event = nullptr;
+    bool recorded = false;
+};
+
+extern "C" int paris_hip_fence_create(paris_hip_ctx* ctx, paris_hip_fence** out)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(out == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    paris_hip_fence* f = new(std::nothrow) paris_hip_fence;
+    if(f == nullptr)
+        return static_cast<int>(hipErrorOutOfMemory);
+    const hipError_t err = hipEventCreateWithFlags(&f->event, hipEventDisableTiming);
+    if(err != hipSuccess)
+    {
+        delete f;
+        return static_cast<int>(err);
+    }
+    *out = f;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_fence_record(paris_hip_ctx* ctx, paris_hip_fence* fence)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(fence == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    PARIS_HIP_TRY(hipEventRecord(fence->event, ctx->stream));
+    fence->recorded = true;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_fence_wait(paris_hip_ctx* ctx, paris_hip_fence* fence)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(fence == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(fence->recorded)
+        PARIS_HIP_TRY(hipEventSynchronize(fence->event));
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_fence_destroy(paris_hip_ctx* ctx, paris_hip_fence* fence)
+{
+    if(fence == nullptr)
+        return PARIS_HIP_SUCCESS;
+    if(ctx != nullptr)
+        (void)hipSetDevice(ctx->device);
+    (void)hipEventDestroy(fence->event);
+    delete fence;
+    return PARIS_HIP_SUCCESS;
+}
+
 // ---- memory ------------------------------------------------------------------------------------------
 
 extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, float** d_ptr,

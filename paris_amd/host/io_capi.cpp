@@ -1,0 +1,110 @@
+// C entry points over the host-only I/O code (HIS, DDBVF, directory listing, angle files) so that the CPU test suite
+// can exercise it through ctypes. No GPU code in here; built as paris_amd/lib/libparis_io.so.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "paris/ddbvf.h"
+#include "paris/his.h"
+#include "paris/source.h"
+
+extern "C" {
+
+// loads every frame of a HIS file; *data receives n_frames*dim_x*dim_y floats (free with paris_io_free).
+// returns 0, or 1 when the file cannot be opened. A non-HIS file gives n_frames = 0.
+int paris_io_his_load(const char* path, uint32_t* n_frames, uint32_t* dim_x, uint32_t* dim_y, float** data)
+{
+    try
+    {
+        const auto frames = paris::his::load(path);
+        *n_frames = static_cast<uint32_t>(frames.size());
+        *dim_x = frames.empty() ? 0 : frames[0].dim_x;
+        *dim_y = frames.empty() ? 0 : frames[0].dim_y;
+        *data = nullptr;
+        if(!frames.empty())
+        {
+            const auto n = static_cast<size_t>(*dim_x) * *dim_y;
+            *data = static_cast<float*>(std::malloc(n * frames.size() * sizeof(float)));
+            for(size_t i = 0; i < frames.size(); ++i)
+                std::memcpy(*data + n * i, frames[i].pixels.data(), n * sizeof(float));
+        }
+        return 0;
+    }
+    catch(const std::exception&) { return 1; }
+}
+
+void paris_io_free(void* p) { std::free(p); }
+
+int paris_io_his_save(const char* path, const float* frames, uint16_t n_frames, uint16_t dim_x, uint16_t dim_y, uint16_t number_type,
+                      uint16_t image_header_size)
+{
+    try { paris::his::save(path, frames, n_frames, dim_x, dim_y, static_cast<paris::his::number_type>(number_type), image_header_size); return 0; }
+    catch(const std::exception&) { return 1; }
+}
+
+// creates <path>.ddbvf and writes one slab; `create` != 0 truncates and writes the header first
+int paris_io_ddbvf_write(const char* path, int create, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, const float* voxels,
+                         uint32_t dim_z_slab, uint32_t first)
+{
+    try
+    {
+        paris::ddbvf::handle_type h;
+        if(create)
+            h = paris::ddbvf::create(path, dim_x, dim_y, dim_z);
+        else
+        {
+            h.reset(new paris::ddbvf::handle);
+            h->dim_x = dim_x; h->dim_y = dim_y; h->dim_z = dim_z; h->offset = 8;
+            h->file = std::fopen((std::string{path} + ".ddbvf").c_str(), "r+b");
+            if(!h->file)
+                return 1;
+        }
+        paris::ddbvf::write(h, voxels, dim_x, dim_y, dim_z_slab, first);
+        return 0;
+    }
+    catch(const std::runtime_error&) { return 2; }
+    catch(const std::exception&) { return 1; }
+}
+
+// angle file -> malloc'd float array
+int paris_io_read_angles(const char* path, uint32_t* n, float** out)
+{
+    try
+    {
+        const auto a = paris::read_angles(path);
+        *n = static_cast<uint32_t>(a.size());
+        *out = static_cast<float*>(std::malloc((a.size() + 1) * sizeof(float)));
+        std::memcpy(*out, a.data(), a.size() * sizeof(float));
+        return 0;
+    }
+    catch(const std::exception&) { return 1; }
+}
+
+// drains a source; returns per-frame idx / phi and the number of skipped files. idx_out/phi_out hold up to cap entries.
+int paris_io_source_scan(const char* dir, int enable_angles, const char* angle_file, uint16_t quality, uint32_t cap, uint32_t* n_frames,
+                         uint32_t* idx_out, float* phi_out, float* first_pixel_out, uint32_t* n_skipped)
+{
+    try
+    {
+        paris::source src{dir, enable_angles != 0, angle_file ? angle_file : "", quality};
+        uint32_t n = 0;
+        while(!src.drained())
+        {
+            const auto p = src.load_next();
+            if(!p.valid())
+                break;
+            if(n < cap)
+            {
+                idx_out[n] = p.idx;
+                phi_out[n] = p.phi;
+                first_pixel_out[n] = p.pixels.empty() ? 0.f : p.pixels[0];
+            }
+            ++n;
+        }
+        *n_frames = n;
+        *n_skipped = static_cast<uint32_t>(src.skipped_files().size());
+        return 0;
+    }
+    catch(const std::exception&) { return 1; }
+}
+}

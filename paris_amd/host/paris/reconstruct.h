@@ -1,0 +1,300 @@
+// The reconstruction driver: tasks, per-device loop, device fan-out -- src/task.{h,cpp}, src/main.cpp:79-109,132-169.
+//
+// What is kept: one task per z-slab (src/task.cpp:38-48), a shared task queue drained by one host thread per device
+// (src/main.cpp:157-167), the stage order load -> weight -> filter -> backproject per projection (:98-105), one
+// sink shared by all threads.
+// What is rebuilt for the GPU:
+//   - the per-projection chain is enqueued asynchronously on the device's stream; the host thread meanwhile reads and
+//     converts the next HIS frame into one of `slots` pinned upload buffers, each guarded by a stream fence, so file
+//     I/O, upload and GPU work overlap instead of running strictly one after the other;
+//   - geometry constants are derived per call and the slab offset is passed per task (Q1, Q2), the source restarts
+//     its frame index per task (Q5), slabs are written at their own slice offset (Q4);
+//   - slab planning is 64-bit and memory driven (paris_hip_make_subvolume_information) with an optional fixed count.
+#ifndef PARIS_AMD_HOST_RECONSTRUCT_H_
+#define PARIS_AMD_HOST_RECONSTRUCT_H_
+
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <future>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "sink.h"
+#include "source.h"
+#include "types.h"
+
+namespace paris
+{
+    // src/program_options.h:34-50 (the parts the hot path needs)
+    struct program_options
+    {
+        detector_geometry det_geo{};
+        bool enable_io = false;
+        std::string input_path, output_path, prefix = "vol";
+        bool enable_roi = false;
+        region_of_interest roi{};
+        bool enable_angles = false;
+        std::string angle_path;
+        std::uint16_t quality = 1;
+        int slabs = 0;     // 0: memory driven (reference behaviour); > 0: fixed slab count
+        int devices = 0;   // 0: all
+        int slots = 4;     // pinned upload buffers per device
+        bool f16 = false;  // store filtered projections as IEEE half before backprojection (BASELINE config 5)
+    };
+
+    // src/task.h:33-57
+    struct task
+    {
+        std::uint32_t id, num;
+        std::string input_path;
+        detector_geometry det_geo;
+        volume_geometry vol_geo;
+        subvolume_geometry subvol_geo;
+        bool enable_roi;
+        region_of_interest roi;
+        bool enable_angles;
+        std::string angle_path;
+        std::uint16_t quality;
+    };
+
+    // src/task.cpp:33-51
+    inline auto make_tasks(const program_options& po, const volume_geometry& vol_geo, const subvolume_info& info) -> std::queue<task>
+    {
+        auto q = std::queue<task>{};
+        for(int i = 0; i < info.num; ++i)
+            q.push(task{static_cast<std::uint32_t>(i), static_cast<std::uint32_t>(info.num), po.input_path, po.det_geo, vol_geo,
+                        info.geo, po.enable_roi, po.roi, po.enable_angles, po.angle_path, po.quality});
+        return q;
+    }
+
+    // the part of GLADOS' task_queue the driver uses: thread-safe pop / empty
+    class task_queue
+    {
+    public:
+        explicit task_queue(std::queue<task> q) : q_{std::move(q)} {}
+        auto pop(task& out) -> bool
+        {
+            std::lock_guard<std::mutex> lock{m_};
+            if(q_.empty())
+                return false;
+            out = q_.front();
+            q_.pop();
+            return true;
+        }
+    private:
+        std::queue<task> q_;
+        std::mutex m_;
+    };
+
+    struct device_report
+    {
+        int device = 0;
+        std::uint32_t tasks = 0, projections = 0;
+        double source_s = 0, enqueue_s = 0, drain_s = 0, save_s = 0;
+        std::vector<std::string> skipped;
+    };
+
+    namespace detail
+    {
+        inline void rt(int rc, const char* what)
+        {
+            if(rc != PARIS_HIP_SUCCESS)
+                throw stage_runtime_error{std::string{what} + " failed: " + paris_hip_strerror(rc)};
+        }
+        using clock = std::chrono::steady_clock;
+        inline double since(clock::time_point t) { return std::chrono::duration<double>(clock::now() - t).count(); }
+    }
+
+    // src/main.cpp:79-109, pipelined
+    inline auto reconstruct(task_queue& queue, int device, sink& out, const program_options& po) -> device_report
+    {
+        using namespace detail;
+        auto rep = device_report{};
+        rep.device = device;
+        paris_hip_ctx* ctx = nullptr;
+        rt(paris_hip_ctx_create(device, nullptr, PARIS_HIP_CTX_DEFAULT, &ctx), "set_device()"); // :87
+
+        const int slots = po.slots < 1 ? 1 : po.slots;
+        const auto n_row = po.det_geo.n_row, n_col = po.det_geo.n_col;
+        const auto frame_bytes = static_cast<std::size_t>(n_row) * n_col * sizeof(float);
+        auto h_buf = std::vector<float*>(slots, nullptr);
+        auto d_buf = std::vector<float*>(slots, nullptr);
+        auto fence = std::vector<paris_hip_fence*>(slots, nullptr);
+        std::size_t d_pitch = 0, h16_pitch = 0;
+        std::uint16_t* d_half = nullptr;
+        float* d_v = nullptr;
+        float* h_v = nullptr;
+        auto cleanup = [&] {
+            for(int s = 0; s < slots; ++s)
+            {
+                paris_hip_fence_destroy(ctx, fence[s]);
+                paris_hip_free(ctx, d_buf[s]);
+                paris_hip_free_host(ctx, h_buf[s]);
+            }
+            paris_hip_free(ctx, d_half);
+            paris_hip_free(ctx, d_v);
+            paris_hip_free_host(ctx, h_v);
+            paris_hip_ctx_destroy(ctx);
+        };
+        try
+        {
+            for(int s = 0; s < slots; ++s)
+            {
+                void* p = nullptr;
+                rt(paris_hip_malloc_host(ctx, frame_bytes, &p), "make_projection_host()");
+                h_buf[s] = static_cast<float*>(p);
+                rt(paris_hip_malloc_projection(ctx, n_row, n_col, &d_buf[s], &d_pitch), "make_projection_device()");
+                rt(paris_hip_fence_create(ctx, &fence[s]), "fence");
+            }
+            if(po.f16)
+            {
+                float* raw = nullptr;
+                h16_pitch = (static_cast<std::size_t>(n_row) * 2 + 255) / 256 * 256;
+                std::size_t got = 0;
+                rt(paris_hip_malloc_projection(ctx, static_cast<std::uint32_t>(h16_pitch / 4), n_col, &raw, &got), "half projection");
+                d_half = reinterpret_cast<std::uint16_t*>(raw);
+                h16_pitch = got;
+            }
+
+            task t{};
+            std::size_t v_cap = 0;
+            while(queue.pop(t)) // :89-91
+            {
+                const bool last = (t.num - t.id) <= 1;                                    // :92
+                const auto dim_z = t.subvol_geo.dim_z + (last ? t.subvol_geo.remainder : 0u); // make_volume: src/make_volume.cpp:32-34
+                const auto offset = t.id * t.subvol_geo.dim_z;                             // :96
+                const auto voxels = static_cast<std::size_t>(t.subvol_geo.dim_x) * t.subvol_geo.dim_y * dim_z;
+                if(voxels > v_cap) // slabs of one run have (almost) the same size: allocate once, re-zero per task
+                {
+                    rt(paris_hip_free(ctx, d_v), "free");
+                    rt(paris_hip_free_host(ctx, h_v), "free");
+                    d_v = nullptr;
+                    h_v = nullptr;
+                    rt(paris_hip_malloc_volume(ctx, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z, &d_v), "make_volume()");
+                    void* p = nullptr;
+                    rt(paris_hip_malloc_host(ctx, voxels * sizeof(float), &p), "make_volume_host()");
+                    h_v = static_cast<float*>(p);
+                    v_cap = voxels;
+                }
+                else
+                    rt(paris_hip_memset_volume(ctx, d_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z), "make_volume()");
+
+                auto t0 = clock::now();
+                source src{t.input_path, t.enable_angles, t.angle_path, t.quality}; // :93 (index restarts per task)
+                rep.source_s += since(t0);
+                int slot = 0;
+                while(!src.drained()) // :98
+                {
+                    t0 = clock::now();
+                    auto p = src.load_next(); // :100
+                    rep.source_s += since(t0);
+                    if(!p.valid())
+                        break;
+                    if(p.dim_x != n_row || p.dim_y != n_col)
+                        throw stage_runtime_error{"projection size does not match the detector geometry"};
+                    t0 = clock::now();
+                    rt(paris_hip_fence_wait(ctx, fence[slot]), "fence wait"); // the upload that last used this slot is done
+                    std::memcpy(h_buf[slot], p.pixels.data(), frame_bytes);
+                    rt(paris_hip_memcpy_projection_h2d(ctx, d_buf[slot], d_pitch, h_buf[slot], static_cast<std::size_t>(n_row) * sizeof(float),
+                                                      n_row, n_col), "load()"); // :101
+                    rt(paris_hip_fence_record(ctx, fence[slot]), "fence record");
+                    rt(paris_hip_stage_weight(ctx, d_buf[slot], d_pitch, n_row, n_col, &t.det_geo), "weight()"); // :102
+                    rt(paris_hip_stage_filter(ctx, d_buf[slot], d_pitch, n_row, n_col, &t.det_geo), "filter()"); // :103
+                    if(po.f16)
+                    {
+                        rt(paris_hip_convert_projection_f16(ctx, d_buf[slot], d_pitch, d_half, h16_pitch, n_row, n_col), "to half");
+                        const float delta_s = t.det_geo.delta_s * t.det_geo.l_px_row, delta_t = t.det_geo.delta_t * t.det_geo.l_px_col;
+                        float sn = 0.f, cs = 0.f;
+                        rt(paris_hip_stage_angle(&t.det_geo, p.idx, t.enable_angles, p.phi, &sn, &cs), "angle");
+                        rt(paris_hip_backproject_f16(ctx, d_half, h16_pitch, n_row, n_col, d_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z,
+                                                     offset, &t.det_geo, &t.vol_geo, t.enable_roi, &t.roi, sn, cs, delta_s, delta_t),
+                           "backproject()");
+                    }
+                    else
+                        rt(paris_hip_stage_backproject(ctx, d_buf[slot], d_pitch, n_row, n_col, p.idx, p.phi, d_v, t.subvol_geo.dim_x,
+                                                       t.subvol_geo.dim_y, dim_z, offset, &t.det_geo, &t.vol_geo, t.enable_angles,
+                                                       t.enable_roi, &t.roi), "backproject()"); // :104
+                    rep.enqueue_s += since(t0);
+                    slot = (slot + 1) % slots;
+                    ++rep.projections;
+                }
+                for(const auto& s : src.skipped_files())
+                    rep.skipped.push_back(s);
+
+                t0 = clock::now();
+                rt(paris_hip_memcpy_volume_d2h(ctx, h_v, d_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z), "copy_d2h()"); // src/sink.cpp:76-77
+                rt(paris_hip_ctx_synchronize(ctx), "synchronize");
+                rep.drain_s += since(t0);
+                t0 = clock::now();
+                out.save(h_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z, offset); // :107
+                rep.save_s += since(t0);
+                ++rep.tasks;
+            }
+        }
+        catch(...)
+        {
+            cleanup();
+            throw;
+        }
+        cleanup();
+        return rep;
+    }
+
+    struct run_report
+    {
+        volume_geometry vol_geo{}, roi_geo{};
+        subvolume_info info{};
+        std::vector<device_report> devices;
+        double wall_s = 0;
+        std::string output_file;
+    };
+
+    // src/main.cpp:120-178
+    inline auto run(const program_options& po) -> run_report
+    {
+        auto r = run_report{};
+        const auto start = detail::clock::now();
+        r.vol_geo = calculate_volume_geometry(po.det_geo); // :122
+        r.roi_geo = r.vol_geo;
+        if(po.enable_roi)                                  // :124-130
+            r.roi_geo = apply_roi(r.vol_geo, po.roi.x1, po.roi.x2, po.roi.y1, po.roi.y2, po.roi.z1, po.roi.z2);
+
+        int n_dev = 0;
+        detail::rt(paris_hip_device_count(&n_dev), "get_devices()"); // :145
+        if(n_dev == 0)
+            throw stage_construction_error{"no HIP device"};
+        if(po.devices > 0 && po.devices < n_dev)
+            n_dev = po.devices;
+
+        if(po.slabs > 0) // fixed split (src/cuda/subvolume_information.cpp:112-116 with a given count)
+        {
+            const auto num = static_cast<std::uint32_t>(po.slabs) > r.roi_geo.dim_z ? r.roi_geo.dim_z : static_cast<std::uint32_t>(po.slabs);
+            r.info.num = static_cast<int>(num);
+            r.info.geo = {r.roi_geo.dim_x, r.roi_geo.dim_y, r.roi_geo.dim_z / num, r.roi_geo.dim_z % num};
+        }
+        else
+            detail::rt(paris_hip_make_subvolume_information(&r.roi_geo, &po.det_geo, n_dev, &r.info), "make_subvolume_information()"); // :137
+
+        task_queue queue{make_tasks(po, r.vol_geo, r.info)}; // :140-141
+        sink out{po.output_path, po.prefix, r.roi_geo};           // :154
+        r.output_file = out.file_path();
+
+        if(n_dev > 1) // :157-167
+        {
+            auto futures = std::vector<std::future<device_report>>{};
+            for(int d = 0; d < n_dev; ++d)
+                futures.emplace_back(std::async(std::launch::async, [&queue, &out, &po, d] { return reconstruct(queue, d, out, po); }));
+            for(auto& f : futures)
+                r.devices.push_back(f.get());
+        }
+        else
+            r.devices.push_back(reconstruct(queue, 0, out, po)); // :169
+        r.wall_s = detail::since(start);
+        return r;
+    }
+}
+
+#endif

@@ -1,0 +1,109 @@
+"""End to end through the rebuilt driver (paris_amd/host/demo/paris.hip = paris_amd/host/paris/reconstruct.h): HIS
+files in a directory -> pipelined load/weight/filter/backproject per slab task -> one DDBVF file, compared with the
+oracle's pipeline on the same frames (filter tolerance)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import formats as F
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "paris_amd", "host", "demo", "paris.hip")
+KAT = (64, 48, 0.2, 0.25, 1.5, -0.75, 100, 200, 45)
+TOL = 1e-5
+
+
+def write_dataset(oracle, d, files=(3, 5), number_type=128):
+    """8 LCG frames split over two HIS files plus a stray non-HIS file."""
+    d.mkdir()
+    i = 0
+    for k, n in enumerate(files):
+        fr = np.stack([oracle.lcg_projection(64, 48, i + j) for j in range(n)])
+        (d / ("proj_%03d.his" % k)).write_bytes(F.his_file_bytes(fr, number_type, 32))
+        i += n
+    (d / "README.txt").write_text("not a projection")
+    geo = d.parent / "geo.ini"
+    geo.write_text("\n".join("%s = %s" % kv for kv in zip(
+        ("n_row", "n_col", "l_px_row", "l_px_col", "delta_s", "delta_t", "d_so", "d_od", "delta_phi"), KAT)) + "\n")
+    return geo
+
+
+def run(args):
+    if not os.path.exists(EXE):
+        pytest.fail("%s missing: run __graft_entry__.build()" % EXE)
+    r = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    return r.stdout
+
+
+def oracle_volume(oracle, idxs, phis=None, roi=None, dims=None):
+    det = oracle.DetectorGeometry(*KAT)
+    vg = oracle.calculate_volume_geometry(det)
+    fs = oracle.filter_size(det.n_row)
+    k = oracle.make_filter(fs, det.l_px_row)
+    vol = np.zeros(dims or (vg.dim_z, vg.dim_y, vg.dim_x), np.float32)
+    for n, i in enumerate(idxs):
+        p = oracle.lcg_projection(64, 48, i)
+        oracle.weight(p, det)
+        oracle.apply_filter(p, k, fs)
+        s, c, ds, dt = oracle.backproject_constants(det, i, phis is not None, phis[n] if phis is not None else 0.0)
+        oracle.backproject(vol, p, 0, det, vg, s, c, ds, dt, roi)
+    return vol
+
+
+def assert_close(got, want):
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= TOL * np.abs(want).max()
+
+
+@pytest.mark.parametrize("slabs", [1, 3])
+def test_his_to_ddbvf(tmp_path, oracle, slabs):
+    geo = write_dataset(oracle, tmp_path / "in")
+    out = run(["--geometry", geo, "--input", tmp_path / "in", "--output", tmp_path / "out", "--name", "kat", "--slabs", slabs])
+    assert "skipped invalid file" in out and "8 projections" in out
+    head, vol = F.ddbvf_read(str(tmp_path / "out" / "kat.ddbvf"))
+    assert head == F.ddbvf_header_bytes(67, 67, 61)
+    assert_close(vol, oracle_volume(oracle, range(8)))
+
+
+def test_roi_quality_and_angles(tmp_path, oracle):
+    geo = write_dataset(oracle, tmp_path / "in", files=(8,))
+    ang = tmp_path / "angles.txt"
+    angles = [3.0, 50.5, 91.25, 140.0, 185.5, 230.0, 270.75, 300.0]
+    ang.write_text("\n".join(str(a) for a in angles))
+    run(["--geometry", geo, "--input", tmp_path / "in", "--output", tmp_path / "o2", "--quality", 2, "--angles", ang,
+         "--roi", "--roi-x1", 8, "--roi-x2", 40, "--roi-y1", 4, "--roi-y2", 36, "--roi-z1", 10, "--roi-z2", 30, "--slabs", 2])
+    _, vol = F.ddbvf_read(str(tmp_path / "o2" / "vol.ddbvf"))
+    roi = oracle.RegionOfInterest(8, 40, 4, 36, 10, 30)
+    want = oracle_volume(oracle, [0, 2, 4, 6], [angles[i] for i in (0, 2, 4, 6)], roi, (20, 32, 32))
+    assert_close(vol, want)
+
+
+def test_ushort_frames_and_memory_driven_split(tmp_path, oracle):
+    """16-bit detector frames (the usual HIS payload) and the default slab planning (no --slabs)."""
+    d = tmp_path / "in"
+    d.mkdir()
+    fr = np.stack([(oracle.lcg_projection(64, 48, i) * 60000).astype(np.uint16) for i in range(4)])
+    (d / "scan.his").write_bytes(F.his_file_bytes(fr, 4, 32))
+    geo = tmp_path / "geo.ini"
+    geo.write_text("\n".join("%s = %s" % kv for kv in zip(
+        ("n_row", "n_col", "l_px_row", "l_px_col", "delta_s", "delta_t", "d_so", "d_od", "delta_phi"), KAT)) + "\n")
+    out = run(["--geometry", geo, "--input", d, "--output", tmp_path / "o3", "--devices", 1])
+    assert "(1 slab)" in out
+    _, vol = F.ddbvf_read(str(tmp_path / "o3" / "vol.ddbvf"))
+    det = oracle.DetectorGeometry(*KAT)
+    vg = oracle.calculate_volume_geometry(det)
+    want = oracle.reconstruct(det, vg, 4, projections=[f.astype(np.float32) for f in fr])
+    assert_close(vol, want)
+
+
+def test_missing_geometry_key_fails_like_the_reference(tmp_path):
+    geo = tmp_path / "geo.ini"
+    geo.write_text("n_row = 64\n")
+    r = subprocess.run([EXE, "--geometry", str(geo), "--input", str(tmp_path), "--output", str(tmp_path / "o")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "required but missing" in r.stderr

@@ -1,0 +1,152 @@
+"""HIS projection reader/writer, DDBVF sink, directory source and angle files of the C++ host layer
+(paris_amd/host/paris/{his,ddbvf,source,sink}.h through paris_amd/lib/libparis_io.so), checked against the format
+restatement in oracle/formats.py. Pure host code: runs without a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import formats as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_fp = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+
+
+@pytest.fixture(scope="module")
+def io():
+    lib = C.CDLL(os.path.join(ROOT, "paris_amd", "lib", "libparis_io.so"))
+    lib.paris_io_his_load.argtypes = [C.c_char_p, _u32p, _u32p, _u32p, C.POINTER(_fp)]
+    lib.paris_io_free.argtypes = [C.c_void_p]
+    lib.paris_io_his_save.argtypes = [C.c_char_p, _fp, C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint16]
+    lib.paris_io_ddbvf_write.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _fp, C.c_uint32, C.c_uint32]
+    lib.paris_io_read_angles.argtypes = [C.c_char_p, _u32p, C.POINTER(_fp)]
+    lib.paris_io_source_scan.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_uint16, C.c_uint32, _u32p, _u32p, _fp, _fp, _u32p]
+    return lib
+
+
+def his_load(io, path):
+    n, w, h, data = C.c_uint32(), C.c_uint32(), C.c_uint32(), _fp()
+    rc = io.paris_io_his_load(str(path).encode(), C.byref(n), C.byref(w), C.byref(h), C.byref(data))
+    if rc:
+        raise OSError("cannot open")
+    if n.value == 0:
+        return []
+    a = np.ctypeslib.as_array(data, shape=(n.value, h.value, w.value)).copy()
+    io.paris_io_free(data)
+    return list(a)
+
+
+@pytest.mark.parametrize("number_type", [2, 4, 32, 64, 128])
+@pytest.mark.parametrize("image_header", [0, 32])
+def test_his_reader_all_number_types(io, tmp_path, number_type, image_header):
+    rng = np.random.default_rng(number_type)
+    hi = {2: 255, 4: 65535, 32: 2 ** 32 - 1, 64: 1e6, 128: 1e6}[number_type]
+    frames = (rng.random((3, 5, 7)) * hi).astype(F.HIS_TYPES[number_type])
+    p = tmp_path / "a.his"
+    p.write_bytes(F.his_file_bytes(frames, number_type, image_header, ulx=3, uly=9))  # rectangle need not start at 1
+    got = his_load(io, p)
+    want = F.his_read(p)
+    assert len(got) == 3 == len(want)
+    for g, w_, f in zip(got, want, frames):
+        assert np.array_equal(g, w_) and np.array_equal(g, f.astype(np.float32))
+
+
+def test_his_reader_rejects_what_the_reference_rejects(io, tmp_path):
+    good = np.ones((1, 2, 2), np.float32)
+    cases = {"wrong_id.his": F.his_file_bytes(good, 128, file_type=0x7001),
+             "wrong_header_size.his": F.his_file_bytes(good, 128, header_size=100),
+             "type_not_implemented.his": F.his_file_bytes(good, 0xFFFF),
+             "unknown_type.his": F.his_file_bytes(good, 8),
+             "empty.his": b"", "text.txt": b"hello"}
+    for name, raw in cases.items():
+        p = tmp_path / name
+        p.write_bytes(raw)
+        assert his_load(io, p) == [] == F.his_read(p), name
+    with pytest.raises(OSError):
+        his_load(io, tmp_path / "missing.his")
+
+
+def test_his_writer_round_trip(io, tmp_path):
+    rng = np.random.default_rng(0)
+    frames = rng.random((4, 6, 10), dtype=np.float32)
+    for number_type, conv in ((128, np.float32), (4, np.uint16), (64, np.float64)):
+        src = (frames * 1000).astype(np.float32)
+        p = tmp_path / ("w%d.his" % number_type)
+        assert io.paris_io_his_save(str(p).encode(), src.ctypes.data_as(_fp), 4, 10, 6, number_type, 32) == 0
+        want = [f.astype(conv).astype(np.float32) for f in src]
+        for got, a, b in zip(F.his_read(p), his_load(io, p), want):  # oracle reader and own reader agree with the input
+            assert np.array_equal(got, a) and np.array_equal(a, b)
+
+
+def test_ddbvf_layout_and_slab_offsets(io, tmp_path):
+    dx, dy, dz = 5, 3, 7
+    vol = np.arange(dx * dy * dz, dtype=np.float32).reshape(dz, dy, dx)
+    base = str(tmp_path / "vol")
+    # three slabs written out of order at their own first slice (the reference writes all at 0: SURVEY Q4)
+    for create, (z0, z1) in ((1, (4, 7)), (0, (0, 2)), (0, (2, 4))):
+        slab = np.ascontiguousarray(vol[z0:z1])
+        assert io.paris_io_ddbvf_write(base.encode(), create, dx, dy, dz, slab.ctypes.data_as(_fp), z1 - z0, z0) == 0
+    head, data = F.ddbvf_read(base + ".ddbvf")
+    assert head == F.ddbvf_header_bytes(dx, dy, dz)  # byte-exact 32-byte header (int version: Q13)
+    assert np.array_equal(data, vol)
+    assert os.path.getsize(base + ".ddbvf") == 32 + vol.nbytes
+    # reference error behaviour: start out of bounds / wrong dims -> runtime_error (src/ddbvf.cpp:131-135)
+    assert io.paris_io_ddbvf_write(base.encode(), 0, dx, dy, dz, vol.ctypes.data_as(_fp), 1, dz) == 2
+    assert io.paris_io_ddbvf_write(base.encode(), 0, dx, dy, dz, vol.ctypes.data_as(_fp), dz + 1, 0) == 2
+
+
+def read_angles(io, path):
+    n, data = C.c_uint32(), _fp()
+    assert io.paris_io_read_angles(str(path).encode(), C.byref(n), C.byref(data)) == 0
+    a = [data[i] for i in range(n.value)]
+    io.paris_io_free(data)
+    return a
+
+
+def test_angle_file_quirks(io, tmp_path):
+    p = tmp_path / "angles.txt"
+    p.write_text("0.5\n1.5\n2.25")            # ends right after the last digit: exactly three values
+    assert read_angles(io, p) == [0.5, 1.5, 2.25]
+    p.write_text("0.5\n1.5\n2.25\n")          # trailing newline: the reference's loop appends one 0 (Q15)
+    assert read_angles(io, p) == [0.5, 1.5, 2.25, 0.0]
+    p.write_text("0,5 1,5\n2,25\n")           # decimal comma (de_DE) when the first line has a ','
+    assert read_angles(io, p) == [0.5, 1.5, 2.25, 0.0]
+    assert read_angles(io, tmp_path / "missing.txt") == []  # unopenable: defaults are used (src/source.cpp:44-48)
+
+
+def test_source_order_stride_and_skips(io, tmp_path):
+    d = tmp_path / "proj"
+    d.mkdir()
+    # three files, 2 + 3 + 1 frames; first pixel encodes the global frame number; names force the sort order
+    k = 0
+    for name, n in (("b_002.his", 3), ("a_001.his", 2), ("c_003.his", 1)):
+        pass
+    for name, n in (("a_001.his", 2), ("b_002.his", 3), ("c_003.his", 1)):
+        fr = np.zeros((n, 2, 2), np.float32)
+        for i in range(n):
+            fr[i, 0, 0] = k
+            k += 1
+        (d / name).write_bytes(F.his_file_bytes(fr, 128, 32))
+    (d / "a_000_notes.txt").write_text("not a projection")  # sorted first, skipped with a warning
+    ang = tmp_path / "ang.txt"
+    ang.write_text(" ".join(str(10.0 * i) for i in range(6)))
+
+    def scan(quality, angles):
+        cap = 16
+        n, skipped = C.c_uint32(), C.c_uint32()
+        idx = (C.c_uint32 * cap)()
+        phi = (C.c_float * cap)()
+        first = (C.c_float * cap)()
+        rc = io.paris_io_source_scan(str(d).encode(), int(angles), str(ang).encode(), quality, cap, C.byref(n), idx, phi, first,
+                                     C.byref(skipped))
+        assert rc == 0
+        return list(idx[:n.value]), list(phi[:n.value]), list(first[:n.value]), skipped.value
+
+    idx, phi, first, skipped = scan(1, False)
+    assert idx == [0, 1, 2, 3, 4, 5] and first == [0, 1, 2, 3, 4, 5] and skipped == 1 and phi == [0.0] * 6
+    idx, phi, first, skipped = scan(2, True)   # quality stride keeps the original index (src/source.cpp:105-113)
+    assert idx == [0, 2, 4] and first == [0, 2, 4] and phi == [0.0, 20.0, 40.0]
+    idx, _, _, _ = scan(4, False)
+    assert idx == [0, 4]
