@@ -150,6 +150,10 @@ def main():
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--tz", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of the N > 1 path "
+                    "with several ranks sharing one GPU)")
+    ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default: LOCAL_RANK)")
+    ap.add_argument("--slices", type=int, default=0, help="rehearsal only: cap the volume depth (0 = the workload's)")
     args = ap.parse_args()
 
     import torch
@@ -162,23 +166,30 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible -- the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = args.device if args.device >= 0 else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     from paris_amd import backend as B
     from paris_amd import sharding
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.slices > 0:
+        w["vol"] = (w["vol"][0], w["vol"][1], min(args.slices, w["vol"][2]))
+        w["name"] += " [rehearsal: %d slices]" % w["vol"][2]
     det, vol_geo = geometry(B, w)
     info = sharding.make_subvolume_info(vol_geo, world)  # one z-slab per rank
     z_first, z_count = sharding.slab_of_task(info, rank)
 
     stream = torch.cuda.current_stream(dev).cuda_stream
-    be = B.Backend(local_rank, stream=stream, synchronous=False)
+    be = B.Backend(dev_index, stream=stream, synchronous=False)
     be.set_backproject_tuning(args.vx, args.unroll, args.tz, args.lds_bytes)
 
     n_row, n_col = w["n_row"], w["n_col"]
@@ -202,7 +213,10 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if args.dist_backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
 
     for s in range(args.warmup):
         step(s)
@@ -219,7 +233,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
