@@ -180,10 +180,11 @@ int paris_hip_backproject_f16(paris_hip_ctx* ctx, const uint16_t* d_p, size_t p_
                               const paris_region_of_interest* roi, float sin_phi, float cos_phi, float delta_s,
                               float delta_t);
 
-/* Extension (no reference counterpart): backprojects n_proj projections in one launch; projection i is at
- * d_p + i * p_stride_bytes. The per-voxel sum is accumulated in projection order, so the result is
- * bit-identical to n_proj successive paris_hip_backproject calls while the volume is read and written
- * once per `batch` projections instead of once per projection. */
+/* Extension (no reference counterpart): backprojects n_proj projections per launch (fused kernel, up to 32 per
+ * launch, more are split); projection i is at d_p + i * p_stride_bytes. Every voxel's sum is accumulated in
+ * projection order in registers, so the result is bit-identical to n_proj successive paris_hip_backproject calls
+ * while the volume is read and written once per launch: 8 / n_proj bytes of HBM traffic per voxel-update. Volumes
+ * that are not 16-byte aligned with dim_x % 4 == 0 take one launch per projection. */
 int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, size_t p_stride_bytes,
                                 uint32_t n_proj, uint32_t p_dim_x, uint32_t p_dim_y, float* d_v,
                                 uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
@@ -231,7 +232,8 @@ int paris_hip_backproject_timing_arm(paris_hip_ctx* ctx, uint32_t capacity);
 int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* ms, uint32_t max_n, uint32_t* n_out);
 /* Selects the backprojection kernel: 0 = default (currently the tile kernel), 1 = one-thread-per-voxel gather kernel
  * without LDS (slow, for cross-checking), 2 = tile kernel (z-walk per workgroup), 3 = slice kernel (one slice per
- * wave; needs a 16-byte aligned volume with dim_x % 4 == 0, else falls back to 2). All give identical bits. */
+ * wave; needs a 16-byte aligned volume with dim_x % 4 == 0, else falls back to 2). All give identical bits.
+ * paris_hip_backproject_batch uses its fused kernel under variant 0 and runs one launch per projection otherwise. */
 int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant);
 /* Tuning knobs of the LDS-staged kernel; 0 keeps the default. vx: voxels per lane along x (1, 2, 4; capped by
  * the volume's alignment), unroll: z slices in flight per lane (1, 2, 4), tz: slices per tile, lds_bytes: LDS

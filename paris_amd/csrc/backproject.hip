@@ -18,8 +18,10 @@
 //     registers; per z step only v is recomputed (src/openmp/backprojection.cpp:130-133).
 #include "paris_hip_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 namespace
 {
@@ -299,9 +301,17 @@ namespace
         float ymax;     // p_dim_y, or -inf when the column's x taps are outside the detector
         int xoff;       // LDS column of the left tap, or -1 when it is not inside the staged box
         int x1i;        // detector column of the left tap (global-memory path)
+        bool fast;      // every valid tap of this column, over the tile's whole z range, lies inside the staged box
     };
 
-    __device__ __forceinline__ Column make_column(const BpParams& g, const Box& b, uint32_t K, uint32_t L)
+    // z_first / z_last: centred z of the tile's first and last slice. The per-slice coordinate v is a monotone
+    // function of the slice index for a fixed column (every step of its evaluation -- multiply by factor, subtract,
+    // divide by the pitch, subtract 0.5, each rounded to nearest -- is monotone), so the rows touched over the tile
+    // lie between the rows touched at its two end slices: `fast` is decided from those two evaluations alone, with
+    // the very expression the slice loop uses, and needs no error bound.
+    template <bool FD>
+    __device__ __forceinline__ Column make_column(const BpParams& g, const Box& b, uint32_t K, uint32_t L, float z_first,
+                                                  float z_last)
     {
         const ColConst c = column_constants(g, K, L);
         const float x1 = floorf(c.h); // :55-58
@@ -318,11 +328,21 @@ namespace
         col.x1i = static_cast<int>(x1);
         const int rel = col.x1i - b.bx0;
         col.xoff = (x_valid && rel >= 0 && rel <= b.bw - 2) ? rel : -1;
+
+        const float va = v_coordinate<FD>(g, z_first, c.factor);
+        const float vb = v_coordinate<FD>(g, z_last, c.factor);
+        const bool ordered = (va == va) && (vb == vb); // no NaN
+        const int r_lo = max(static_cast<int>(floorf(fminf(va, vb))), 0);                              // valid taps start at row 0
+        const int r_hi = min(static_cast<int>(floorf(fmaxf(va, vb))), static_cast<int>(g.p_dim_y) - 2); // and end at dim_y - 2
+        const bool rows_inside = (r_lo > r_hi) || (r_lo >= b.by0 && r_hi <= b.by0 + b.bhs - 2);
+        col.fast = !x_valid || (ordered && col.xoff >= 0 && rows_inside);
         return col;
     }
 
     // one voxel-update: src/openmp/backprojection.cpp:130-140 for slice coordinate z_m of column col
-    template <bool FD>
+    // FAST: the column was proven to stay inside the staged box (Column::fast), so the global-memory path and its
+    // branch are compiled out and the body is straight-line code the scheduler can overlap across voxels.
+    template <bool FD, bool FAST>
     __device__ __forceinline__ float voxel_contribution(const BpParams& g, const Box& b, const float* lds_box, float z_m,
                                                         const Column& col)
     {
@@ -333,22 +353,25 @@ namespace
         const int y1i = static_cast<int>(y1);
         const int rrel = y1i - b.by0;
         const int bhs_m2 = b.bhs - 2;
-        const bool inbox = col.xoff >= 0 && rrel >= 0 && rrel <= bhs_m2;
         const int rc = min(max(rrel, 0), max(bhs_m2, 0));
         const int base = rc * b.stride + max(col.xoff, 0);
         float q11 = lds_box[base];
         float q21 = lds_box[base + 1];
         float q12 = lds_box[base + b.stride];
         float q22 = lds_box[base + b.stride + 1];
-        if(valid && !inbox)
+        if(!FAST)
         {
-            // tap outside the staged box: read the detector directly (valid => in bounds). The volatile reads in
-            // read_pixel keep the compiler from merging these loads with the LDS reads into flat loads
-            const size_t at = static_cast<size_t>(y1i) * g.p_pitch + col.x1i;
-            q11 = read_pixel(g, at);
-            q21 = read_pixel(g, at + 1);
-            q12 = read_pixel(g, at + g.p_pitch);
-            q22 = read_pixel(g, at + g.p_pitch + 1);
+            const bool inbox = col.xoff >= 0 && rrel >= 0 && rrel <= bhs_m2;
+            if(valid && !inbox)
+            {
+                // tap outside the staged box: read the detector directly (valid => in bounds). The volatile reads in
+                // read_pixel keep the compiler from merging these loads with the LDS reads into flat loads
+                const size_t at = static_cast<size_t>(y1i) * g.p_pitch + col.x1i;
+                q11 = read_pixel(g, at);
+                q21 = read_pixel(g, at + 1);
+                q12 = read_pixel(g, at + g.p_pitch);
+                q22 = read_pixel(g, at + g.p_pitch + 1);
+            }
         }
         const float interp_y1 = col.wx2 * q11 + col.wx1 * q21; // :77
         const float interp_y2 = col.wx2 * q12 + col.wx1 * q22; // :78
@@ -397,43 +420,55 @@ namespace
         if(k >= g.v_dim_x || l >= g.v_dim_y)
             return;
 
+        const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
+        const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
         Column col[VX];
+        bool all_fast = true;
 #pragma unroll
         for(int j = 0; j < VX; ++j)
-            col[j] = make_column(g, box, g.k_off + k + j, g.l_off + l);
+        {
+            col[j] = make_column<FD>(g, box, g.k_off + k + j, g.l_off + l, z_first, z_last);
+            all_fast = all_fast && col[j].fast;
+        }
 
         using vec_t = typename vec_of<VX>::type;
         const size_t slice = static_cast<size_t>(g.v_dim_x) * g.v_dim_y;
         float* vp = g.vol + (static_cast<size_t>(m0) * g.v_dim_y + l) * g.v_dim_x + k;
         const uint32_t mcount = m1 - m0 + 1u;
 
-        auto update = [&](vec_t& acc, uint32_t m_local) {
-            const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + m_local) * g.l_vx_z; // :118
+        auto walk = [&](auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            auto update = [&](vec_t& acc, uint32_t m_local) {
+                const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + m_local) * g.l_vx_z; // :118
 #pragma unroll
-            for(int j = 0; j < VX; ++j)
-                elem<VX>(acc, j) += voxel_contribution<FD>(g, box, lds, z_m, col[j]);
+                for(int j = 0; j < VX; ++j)
+                    elem<VX>(acc, j) += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[j]);
+            };
+            uint32_t mm = 0;
+            for(; mm + UNROLL <= mcount; mm += UNROLL)
+            {
+                vec_t acc[UNROLL];
+#pragma unroll
+                for(int i = 0; i < UNROLL; ++i)
+                    acc[i] = load_voxels<VX, NT>(vp + (mm + i) * slice);
+#pragma unroll
+                for(int i = 0; i < UNROLL; ++i)
+                    update(acc[i], mm + i);
+#pragma unroll
+                for(int i = 0; i < UNROLL; ++i)
+                    store_voxels<VX, NT>(vp + (mm + i) * slice, acc[i]);
+            }
+            for(; mm < mcount; ++mm)
+            {
+                vec_t acc = load_voxels<VX, NT>(vp + mm * slice);
+                update(acc, mm);
+                store_voxels<VX, NT>(vp + mm * slice, acc);
+            }
         };
-
-        uint32_t mm = 0;
-        for(; mm + UNROLL <= mcount; mm += UNROLL)
-        {
-            vec_t acc[UNROLL];
-#pragma unroll
-            for(int i = 0; i < UNROLL; ++i)
-                acc[i] = load_voxels<VX, NT>(vp + (mm + i) * slice);
-#pragma unroll
-            for(int i = 0; i < UNROLL; ++i)
-                update(acc[i], mm + i);
-#pragma unroll
-            for(int i = 0; i < UNROLL; ++i)
-                store_voxels<VX, NT>(vp + (mm + i) * slice, acc[i]);
-        }
-        for(; mm < mcount; ++mm)
-        {
-            vec_t acc = load_voxels<VX, NT>(vp + mm * slice);
-            update(acc, mm);
-            store_voxels<VX, NT>(vp + mm * slice, acc);
-        }
+        if(all_fast)
+            walk(std::true_type{});
+        else
+            walk(std::false_type{}); // some tap of this lane may leave the staged box: per-voxel check + global path
     }
 
     // --------------------------------------------------------------------------------------------
@@ -480,7 +515,7 @@ namespace
         for(uint32_t c = tid; c < NCOL; c += NW * 64u)
         {
             const uint32_t cx = c & 63u, cy = c >> 6;
-            const Column col = make_column(g, box, g.k_off + min(k0 + cx, k1), g.l_off + min(l0 + cy, l1));
+            const Column col = make_column<FD>(g, box, g.k_off + min(k0 + cx, k1), g.l_off + min(l0 + cy, l1), 0.f, 0.f);
             c_factor[c] = col.factor;
             c_u[c] = col.u;
             c_wx1[c] = col.wx1;
@@ -520,15 +555,118 @@ namespace
             const float4 y4 = *reinterpret_cast<const float4*>(c_ymax + c);
             const int4 o4 = *reinterpret_cast<const int4*>(c_xoff + c);
             const int4 i4 = *reinterpret_cast<const int4*>(c_x1i + c);
-            acc[r].x += voxel_contribution<FD>(g, box, lds_box, z_m, Column{f4.x, u4.x, a4.x, b4.x, y4.x, o4.x, i4.x});
-            acc[r].y += voxel_contribution<FD>(g, box, lds_box, z_m, Column{f4.y, u4.y, a4.y, b4.y, y4.y, o4.y, i4.y});
-            acc[r].z += voxel_contribution<FD>(g, box, lds_box, z_m, Column{f4.z, u4.z, a4.z, b4.z, y4.z, o4.z, i4.z});
-            acc[r].w += voxel_contribution<FD>(g, box, lds_box, z_m, Column{f4.w, u4.w, a4.w, b4.w, y4.w, o4.w, i4.w});
+            acc[r].x += voxel_contribution<FD, false>(g, box, lds_box, z_m, Column{f4.x, u4.x, a4.x, b4.x, y4.x, o4.x, i4.x, false});
+            acc[r].y += voxel_contribution<FD, false>(g, box, lds_box, z_m, Column{f4.y, u4.y, a4.y, b4.y, y4.y, o4.y, i4.y, false});
+            acc[r].z += voxel_contribution<FD, false>(g, box, lds_box, z_m, Column{f4.z, u4.z, a4.z, b4.z, y4.z, o4.z, i4.z, false});
+            acc[r].w += voxel_contribution<FD, false>(g, box, lds_box, z_m, Column{f4.w, u4.w, a4.w, b4.w, y4.w, o4.w, i4.w, false});
         }
 #pragma unroll
         for(int r = 0; r < RPL; ++r)
             if(l0 + yy + 4u * r < g.v_dim_y)
                 store_voxels<4, NT>(vp + r * row4, acc[r]);
+    }
+
+    // --------------------------------------------------------------------------------------------
+    // Fused kernel (extension: paris_hip_backproject_batch). One launch adds n_proj projections: a lane keeps its
+    // 4 x TZ voxels in registers, and for every projection in turn the workgroup stages that projection's box,
+    // rebuilds the column state and adds the TZ contributions -- in projection order, so every voxel sees exactly
+    // the additions, in exactly the order, of n_proj single launches (bit-identical), while the volume is read
+    // and written once per batch: 8 / n_proj bytes per voxel-update. With the HBM term gone the kernel is bound by
+    // vector ALU issue (about 40 instructions per voxel-update plus the per-projection column setup).
+    // --------------------------------------------------------------------------------------------
+    constexpr int FUSED_MAX = 32;
+
+    struct FusedParams
+    {
+        BpParams g;           // proj = first projection; sin/cos overwritten per projection
+        uint32_t n_proj;
+        uint32_t proj_stride; // pixels between consecutive projections
+        float sin_phi[FUSED_MAX];
+        float cos_phi[FUSED_MAX];
+    };
+
+    template <int TZ, bool NT, bool FD>
+    __global__ void __launch_bounds__(256) bp_fused_kernel(const FusedParams fp)
+    {
+        extern __shared__ __attribute__((aligned(16))) float lds[];
+        BpParams g = fp.g;
+
+        const uint32_t tid = threadIdx.x;
+        const uint32_t lane = tid & 63u;
+        const uint32_t wave = tid >> 6;
+
+        uint32_t bx, by, bz;
+        if(!tile_of_block(g, blockIdx.x, bx, by, bz))
+            return;
+        const uint32_t k0 = bx * 64u;
+        const uint32_t l0 = by * 16u;
+        const uint32_t m0 = bz * TZ;
+        const uint32_t k1 = min(k0 + 63u, g.v_dim_x - 1u);
+        const uint32_t l1 = min(l0 + 15u, g.v_dim_y - 1u);
+        const uint32_t m1 = min(m0 + TZ - 1u, g.v_dim_z - 1u);
+        const uint32_t mcount = m1 - m0 + 1u;
+
+        const uint32_t xq = lane & 15u, yy = lane >> 4;
+        const uint32_t k = k0 + xq * 4u;
+        const uint32_t l = l0 + wave * 4u + yy;
+        const bool active = k < g.v_dim_x && l < g.v_dim_y; // inactive lanes still take part in the barriers
+
+        const size_t slice = static_cast<size_t>(g.v_dim_x) * g.v_dim_y;
+        float* vp = g.vol + (static_cast<size_t>(m0) * g.v_dim_y + l) * g.v_dim_x + k;
+        float4 acc[TZ];
+#pragma unroll
+        for(int z = 0; z < TZ; ++z)
+            if(active && static_cast<uint32_t>(z) < mcount)
+                acc[z] = load_voxels<4, NT>(vp + z * slice);
+
+        const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
+        const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
+        const char* base = static_cast<const char*>(fp.g.proj);
+        const size_t px = g.proj_f16 ? 2u : 4u;
+        for(uint32_t p = 0; p < fp.n_proj; ++p)
+        {
+            g.sin_phi = fp.sin_phi[p];
+            g.cos_phi = fp.cos_phi[p];
+            g.proj = base + static_cast<size_t>(p) * fp.proj_stride * px;
+            const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats);
+            __syncthreads(); // the previous projection's taps are done with the LDS box
+            stage_box(g, box, lds, wave, 4u, lane);
+            __syncthreads();
+            if(active)
+            {
+                Column col[4];
+                bool all_fast = true;
+#pragma unroll
+                for(int j = 0; j < 4; ++j)
+                {
+                    col[j] = make_column<FD>(g, box, g.k_off + k + j, g.l_off + l, z_first, z_last);
+                    all_fast = all_fast && col[j].fast;
+                }
+                auto add_projection = [&](auto fast_tag) {
+                    constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+                    for(int z = 0; z < TZ; ++z)
+                    {
+                        if(static_cast<uint32_t>(z) < mcount) // uniform; no break, so the loop unrolls and acc stays in registers
+                        {
+                            const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + z) * g.l_vx_z; // :118
+                            acc[z].x += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[0]);
+                            acc[z].y += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[1]);
+                            acc[z].z += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[2]);
+                            acc[z].w += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[3]);
+                        }
+                    }
+                };
+                if(all_fast)
+                    add_projection(std::true_type{});
+                else
+                    add_projection(std::false_type{});
+            }
+        }
+#pragma unroll
+        for(int z = 0; z < TZ; ++z)
+            if(active && static_cast<uint32_t>(z) < mcount)
+                store_voxels<4, NT>(vp + z * slice, acc[z]);
     }
 
     // --------------------------------------------------------------------------------------------
@@ -668,6 +806,33 @@ namespace
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     }
 
+    template <int TZ, bool NT, bool FD>
+    void launch_fused(FusedParams& fp, hipStream_t stream)
+    {
+        BpParams& g = fp.g;
+        g.tz = TZ;
+        g.ntx = (g.v_dim_x + 63u) / 64u;
+        g.nty = (g.v_dim_y + 15u) / 16u;
+        g.ntz = (g.v_dim_z + TZ - 1u) / TZ;
+        uint32_t blocks = g.ntx * g.nty * g.ntz;
+        if(g.order == 5u)
+            blocks = ((blocks + 7u) / 8u) * 8u;
+        hipLaunchKernelGGL((bp_fused_kernel<TZ, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, fp);
+    }
+
+    template <int TZ>
+    void launch_fused_flags(FusedParams& fp, bool nt, bool fd, hipStream_t stream)
+    {
+        if(nt && fd)
+            launch_fused<TZ, true, true>(fp, stream);
+        else if(nt)
+            launch_fused<TZ, true, false>(fp, stream);
+        else if(fd)
+            launch_fused<TZ, false, true>(fp, stream);
+        else
+            launch_fused<TZ, false, false>(fp, stream);
+    }
+
     // Is div_by_constant exact for this divisor? Checked once per ctx and divisor on the GPU (about 2 ms).
     int fastdiv_is_exact(paris_hip_ctx* ctx, float c, bool* ok)
     {
@@ -695,13 +860,15 @@ namespace
     }
 }
 
-static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, uint32_t p_dim_x,
-                            uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z,
-                            uint32_t v_offset, const paris_detector_geometry* det_geo,
-                            const paris_volume_geometry* vol_geo, int enable_roi, const paris_region_of_interest* roi,
-                            float sin_phi, float cos_phi, float delta_s, float delta_t)
+// validates the arguments of one backprojection and derives the kernel parameters; *skip = true for an empty volume
+static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, uint32_t p_dim_x, uint32_t p_dim_y,
+                       float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
+                       const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
+                       const paris_region_of_interest* roi, float sin_phi, float cos_phi, float delta_s, float delta_t,
+                       BpParams& g, bool& fd, bool& skip)
 {
     const size_t px = f16 ? sizeof(uint16_t) : sizeof(float);
+    skip = false;
     if(int rc = paris_hip_bind(ctx))
         return rc;
     if(d_p == nullptr || d_v == nullptr || det_geo == nullptr || vol_geo == nullptr || (enable_roi && roi == nullptr))
@@ -709,16 +876,19 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
     if(p_dim_x == 0 || p_dim_y == 0 || p_pitch < static_cast<size_t>(p_dim_x) * px || p_pitch % px != 0)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(v_dim_x == 0 || v_dim_y == 0 || v_dim_z == 0)
-        return paris_hip_finish(ctx);
+    {
+        skip = true;
+        return PARIS_HIP_SUCCESS;
+    }
     const uint32_t tz = ctx->bp_tz ? ctx->bp_tz : TZ_DEFAULT;
     {
         // the 1-D grid must hold every tile (narrowest tile: 64 x 4 x tz)
-        const uint64_t tiles = static_cast<uint64_t>((v_dim_x + 63u) / 64u) * ((v_dim_y + 3u) / 4u) * ((v_dim_z + tz - 1u) / tz);
+        const uint64_t tiles = static_cast<uint64_t>((v_dim_x + 63u) / 64u) * ((v_dim_y + 3u) / 4u) * ((v_dim_z + std::min(tz, 8u) - 1u) / std::min(tz, 8u));
         if(tiles > 0x7fffff00ull)
             return PARIS_HIP_ERROR_UNSUPPORTED;
     }
 
-    BpParams g{};
+    g = BpParams{};
     g.proj = d_p;
     g.proj_f16 = f16 ? 1u : 0u;
     g.vol = d_v;
@@ -746,7 +916,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
     g.min_h = detector_min(p_dim_x, g.l_px_x, delta_s);
     g.min_v = detector_min(p_dim_y, g.l_px_y, delta_t);
     g.rcp_l_px_y = 1.f / g.l_px_y;
-    bool fd = false;
+    fd = false;
     if(ctx->bp_fastdiv != 0)
         if(int rc = fastdiv_is_exact(ctx, g.l_px_y, &fd))
             return rc;
@@ -755,6 +925,33 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
     g.tz = tz;
     g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : 5u;
+    return PARIS_HIP_SUCCESS;
+}
+
+// widest per-lane access the volume's alignment allows
+static int lane_width(const float* d_v, uint32_t v_dim_x)
+{
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(d_v);
+    if(v_dim_x % 4u == 0 && addr % 16u == 0)
+        return 4;
+    if(v_dim_x % 2u == 0 && addr % 8u == 0)
+        return 2;
+    return 1;
+}
+
+static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, uint32_t p_dim_x,
+                            uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z,
+                            uint32_t v_offset, const paris_detector_geometry* det_geo,
+                            const paris_volume_geometry* vol_geo, int enable_roi, const paris_region_of_interest* roi,
+                            float sin_phi, float cos_phi, float delta_s, float delta_t)
+{
+    BpParams g;
+    bool fd = false, skip = false;
+    if(int rc = fill_params(ctx, d_p, f16, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
+                            enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t, g, fd, skip))
+        return rc;
+    if(skip)
+        return paris_hip_finish(ctx);
 
     const size_t ev = static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size());
     PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
@@ -767,13 +964,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
     }
     else
     {
-        // widest per-lane access the volume's alignment allows, unless the tuning knob asks for less
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(d_v);
-        int vx = 1;
-        if(v_dim_x % 4u == 0 && addr % 16u == 0)
-            vx = 4;
-        else if(v_dim_x % 2u == 0 && addr % 8u == 0)
-            vx = 2;
+        int vx = lane_width(d_v, v_dim_x); // unless the tuning knob asks for less
         if(ctx->bp_vx && ctx->bp_vx < vx)
             vx = ctx->bp_vx;
         const int unroll = ctx->bp_unroll ? ctx->bp_unroll : 2;
@@ -861,24 +1052,61 @@ extern "C" int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p,
                                            const paris_region_of_interest* roi, const float* sin_phi,
                                            const float* cos_phi, float delta_s, float delta_t)
 {
-    // Round 1: the batched entry point is the sequence of single-projection launches it is defined to
-    // equal (include/paris_hip.h). A fused multi-projection kernel replaces this loop later.
-    if(sin_phi == nullptr || cos_phi == nullptr || p_stride_bytes % sizeof(float) != 0)
+    if(ctx == nullptr || sin_phi == nullptr || cos_phi == nullptr || p_stride_bytes % sizeof(float) != 0)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    const unsigned saved = ctx ? ctx->flags : 0u;
-    if(ctx)
-        ctx->flags &= ~PARIS_HIP_CTX_SYNCHRONOUS;
-    int rc = PARIS_HIP_SUCCESS;
-    for(uint32_t i = 0; i < n_proj && rc == PARIS_HIP_SUCCESS; ++i)
+    if(n_proj == 0)
+        return paris_hip_finish(ctx);
+
+    // The fused kernel needs 16-byte lanes; any other volume, and the cross-check variants, take the sequence of
+    // single-projection launches that the fused kernel is defined to equal.
+    const bool fused_ok = (ctx->bp_variant == 0 || ctx->bp_variant == 4) && d_v != nullptr && lane_width(d_v, v_dim_x) == 4
+                          && (ctx->bp_vx == 0 || ctx->bp_vx == 4);
+    if(!fused_ok)
     {
-        const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_p) + i * p_stride_bytes);
-        rc = paris_hip_backproject(ctx, p, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset,
-                                   det_geo, vol_geo, enable_roi, roi, sin_phi[i], cos_phi[i], delta_s, delta_t);
-    }
-    if(ctx)
+        const unsigned saved = ctx->flags;
+        ctx->flags &= ~PARIS_HIP_CTX_SYNCHRONOUS;
+        int rc = PARIS_HIP_SUCCESS;
+        for(uint32_t i = 0; i < n_proj && rc == PARIS_HIP_SUCCESS; ++i)
+        {
+            const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_p) + i * p_stride_bytes);
+            rc = paris_hip_backproject(ctx, p, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
+                                       enable_roi, roi, sin_phi[i], cos_phi[i], delta_s, delta_t);
+        }
         ctx->flags = saved;
-    if(rc != PARIS_HIP_SUCCESS)
-        return rc;
+        if(rc != PARIS_HIP_SUCCESS)
+            return rc;
+        return paris_hip_finish(ctx);
+    }
+
+    const bool nt = ctx->bp_nt != 0;
+    const bool tz16 = ctx->bp_tz == 16u;
+    for(uint32_t first = 0; first < n_proj; first += FUSED_MAX)
+    {
+        const uint32_t n = std::min<uint32_t>(FUSED_MAX, n_proj - first);
+        FusedParams fp;
+        bool fd = false, skip = false;
+        const char* p0 = reinterpret_cast<const char*>(d_p) + static_cast<size_t>(first) * p_stride_bytes;
+        if(int rc = fill_params(ctx, p0, false, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
+                                vol_geo, enable_roi, roi, sin_phi[first], cos_phi[first], delta_s, delta_t, fp.g, fd, skip))
+            return rc;
+        if(skip)
+            break;
+        fp.n_proj = n;
+        fp.proj_stride = static_cast<uint32_t>(p_stride_bytes / sizeof(float));
+        for(uint32_t i = 0; i < n; ++i)
+        {
+            fp.sin_phi[i] = sin_phi[first + i];
+            fp.cos_phi[i] = cos_phi[first + i];
+        }
+        const size_t ev = static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size());
+        PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
+        if(tz16)
+            launch_fused_flags<16>(fp, nt, fd, ctx->stream);
+        else
+            launch_fused_flags<8>(fp, nt, fd, ctx->stream);
+        PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
+        ++ctx->bp_launches;
+    }
     return paris_hip_finish(ctx);
 }
 
@@ -896,7 +1124,7 @@ extern "C" int paris_hip_last_backproject_ms(paris_hip_ctx* ctx, float* ms)
 
 extern "C" int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant)
 {
-    if(ctx == nullptr || variant < 0 || variant > 3)
+    if(ctx == nullptr || variant < 0 || variant > 4)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_variant = variant;
     return PARIS_HIP_SUCCESS;

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--angles", default="0,17,45,90,200")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--order", default="0,1,5")
+    ap.add_argument("--fused", default="", help="fused kernel: projections per launch, e.g. 4,8,16 (uses --tz 8|16, --lds)")
     ap.add_argument("--slice", default="", help="slice kernel shapes, e.g. 16x4,8x2 (empty: tile kernel)")
     ap.add_argument("--nt", default="0,1")
     args = ap.parse_args()
@@ -40,6 +41,30 @@ def main():
     angles = [int(a) for a in args.angles.split(",")]
     voxels = float(n) * n * args.slices
     results = []
+    if args.fused:
+        import ctypes as C
+        be.set_backproject_variant(0)
+        nmax = max(int(x) for x in args.fused.split(","))
+        stack = be.make_projection_device(n, n * nmax)
+        hs = B.Projection(rng.random((n * nmax, n), dtype=np.float32), n, n * nmax)
+        be.copy_h2d(hs, stack)
+        for P, tz, lds in itertools.product(*[[int(x) for x in s.split(",")] for s in (args.fused, args.tz, args.lds)]):
+            be.set_backproject_tuning(0, 0, tz, lds)
+            sc = [B.stage_angle(det, 4 * (a + 3 * i)) for i, a in enumerate(range(P))]
+            ms = []
+            for rep in range(args.reps + 1):
+                be.backproject_batch(stack.ptr, stack.pitch, stack.pitch * n, P, n, n, d_v, z_first, det, vg, False, None,
+                                     [s for s, _ in sc], [c for _, c in sc], 0.0, 0.0)
+                t = be.last_backproject_ms()
+                if rep > 0:
+                    ms.append(t)
+            avg = sum(ms) / len(ms)
+            r = dict(kernel="fused", P=P, tz=tz, lds=lds, ms=avg, ms_per_proj=avg / P, gvox=voxels * P / avg / 1e6,
+                     hbm_gbs=(8.0 / P) * voxels * P / avg / 1e6)
+            results.append(r)
+            print(json.dumps(r), flush=True)
+        print("BEST", json.dumps(max(results, key=lambda r: r["gvox"])))
+        return
     shapes = [tuple(int(x) for x in sh.split("x")) for sh in args.slice.split(",") if sh]
     for nw, rpl in shapes:
         be.set_backproject_variant(3)
@@ -78,7 +103,7 @@ def main():
                  gvox=voxels / avg / 1e6)
         results.append(r)
         print(json.dumps(r), flush=True)
-    best = max(results, key=lambda r: r["gbs"])
+    best = max(results, key=lambda r: r.get("gbs", 0))
     print("BEST", json.dumps(best))
 
 
