@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--tz", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
+    ap.add_argument("--fused-steps", type=int, default=4, help="extra steps with the fused multi-projection kernel, "
+                    "reported as fused_extension next to the headline (0 disables)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of the N > 1 path "
                     "with several ranks sharing one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default: LOCAL_RANK)")
@@ -238,6 +240,39 @@ def main():
         elapsed = float(t.item())
 
     kernel_ms = be.backproject_timing_collect()
+
+    # ---- extension, outside the headline: the same step with ONE fused launch per batch (paris_hip_backproject_batch)
+    fused = None
+    if args.fused_steps > 0:
+        sc = [B.stage_angle(det, b) for b in range(w["n_proj"])]
+        stride = work.stride(0) * 4
+
+        def fused_step(s):
+            idx = [(s * args.batch + b) % w["n_proj"] for b in range(args.batch)]
+            for b in range(args.batch):
+                work[b].copy_(raw[b], non_blocking=True)
+                B.weight(be, projs[b], det)
+                B.filter(be, projs[b], det)
+            be.backproject_batch(work.data_ptr(), pitch, stride, args.batch, n_row, n_col, d_vol, z_first, det, vol_geo, False,
+                                 None, [sc[i][0] for i in idx], [sc[i][1] for i in idx], 0.0, 0.0)
+
+        fused_step(0)
+        torch.cuda.synchronize()
+        be.backproject_timing_arm(args.fused_steps)
+        barrier()
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for s in range(args.fused_steps):
+            fused_step(1 + s)
+        torch.cuda.synchronize()
+        barrier()
+        tf = time.perf_counter() - tf0
+        if dist is not None:
+            t = torch.tensor([tf], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tf = float(t.item())
+        fms = be.backproject_timing_collect()
+        fused = {"steps": args.fused_steps, "seconds": tf, "kernel_ms": sum(fms) / max(1, len(fms))}
     voxels_rank = float(z_count) * vol_geo.dim_x * vol_geo.dim_y
     voxels_all = float(vol_geo.dim_z) * vol_geo.dim_x * vol_geo.dim_y
     updates_all = voxels_all * args.batch * args.steps
@@ -276,6 +311,21 @@ def main():
                 "launches_timed": len(kernel_ms),
             },
         }
+        if fused is not None:
+            per_launch = voxels_rank * args.batch
+            out["fused_extension"] = {
+                "what": "same step, but one fused launch adds all %d projections of the batch (paris_hip_backproject_batch; "
+                        "bit-identical volume); not the headline because the plugin boundary is one projection per call"
+                        % args.batch,
+                "value": voxels_all * args.batch * fused["steps"] / fused["seconds"] / 1e9,
+                "unit": "GVoxel-updates/s",
+                "kernel_ms_per_launch": fused["kernel_ms"],
+                "kernel_GVox_per_s_per_gpu": per_launch / (fused["kernel_ms"] * 1e-3) / 1e9 if fused["kernel_ms"] > 0 else 0.0,
+                "algorithmic_bytes_per_update": 8.0 / args.batch,
+                "hbm_GBps": (8.0 * voxels_rank + 4.0 * n_row * n_col * args.batch) / (fused["kernel_ms"] * 1e-3) / 1e9
+                            if fused["kernel_ms"] > 0 else 0.0,
+                "bound": "vector ALU issue (HBM term divided by the batch size)",
+            }
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
         print(json.dumps(out), flush=True)

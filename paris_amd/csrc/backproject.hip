@@ -46,6 +46,7 @@ namespace
         uint32_t tz; // slices per tile
         uint32_t ntx, nty, ntz; // tiles per axis
         uint32_t order;         // workgroup -> tile mapping, see tile_of_block
+        uint32_t store_sc1;     // nontemporal stores also carry sc1 (write-through)
     };
 
     struct ColConst
@@ -132,6 +133,17 @@ namespace
         return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
     }
 
+    // 1-D grid size for the tile mapping in g.order (tile_of_block rejects the padding blocks)
+    inline uint32_t grid_blocks(const BpParams& g)
+    {
+        const uint32_t total = g.ntx * g.nty * g.ntz;
+        if(g.order == 5u)
+            return ((total + 7u) / 8u) * 8u;
+        if(g.order == 8u)
+            return 8u * ((g.nty + 7u) / 8u) * g.ntx * g.ntz;
+        return total;
+    }
+
     // ext-vector twins of float/float2/float4 for the nontemporal builtins
     template <int VX> struct ext_of;
     template <> struct ext_of<1> { typedef float type; };
@@ -147,11 +159,19 @@ namespace
         ext_t e = NT ? __builtin_nontemporal_load(reinterpret_cast<const ext_t*>(p)) : *reinterpret_cast<const ext_t*>(p);
         return *reinterpret_cast<vec_t*>(&e);
     }
-    template <int VX, bool NT> __device__ __forceinline__ void store_voxels(float* p, typename vec_of<VX>::type v)
+    template <int VX, bool NT> __device__ __forceinline__ void store_voxels(float* p, typename vec_of<VX>::type v, bool sc1 = true)
     {
         using ext_t = typename ext_of<VX>::type;
         const ext_t e = *reinterpret_cast<ext_t*>(&v);
-        if(NT)
+        if(NT && VX == 4 && sc1)
+        {
+            // Write-through + nontemporal ("sc1 nt") is the fastest policy for this once-written stream
+            // (tools/membench7.hip: +3 % over "nt" alone). No builtin emits that pair for a plain global store, so the
+            // store is inline asm; hipcc neither counts it (nothing waits on a store) nor pads it: the trailing
+            // s_nop 1 keeps the next instruction from overwriting the four data registers before they are read.
+            asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(e) : "memory");
+        }
+        else if(NT)
             __builtin_nontemporal_store(e, reinterpret_cast<ext_t*>(p));
         else
             *reinterpret_cast<ext_t*>(p) = e;
@@ -162,6 +182,7 @@ namespace
     //   0: x tiles fastest, then y, then z (XCD k keeps hitting the same x columns: slowest)
     //   1: z tiles fastest, then x, then y
     //   5: XCD k sweeps its own contiguous eighth of the (x, y, z) tile sequence
+    //   8: XCD k owns a band of y tiles; x fastest, then z, then y inside the band (fastest: tools/membench5.hip)
     __device__ __forceinline__ bool tile_of_block(const BpParams& g, uint32_t b, uint32_t& bx, uint32_t& by, uint32_t& bz)
     {
         const uint32_t total = g.ntx * g.nty * g.ntz;
@@ -174,6 +195,20 @@ namespace
             bx = b % g.ntx;
             by = b / g.ntx;
             return true;
+        }
+        if(g.order == 8u)
+        {
+            // XCD k owns the contiguous band k of y tiles for the whole slab; inside the band x runs fastest, then the
+            // z tile, then y: the tiles in flight on one XCD share their detector rows and sit in few DRAM pages
+            const uint32_t band = (g.nty + 7u) / 8u;
+            const uint32_t xcd = b % 8u;
+            uint32_t r = b / 8u;
+            bx = r % g.ntx;
+            r /= g.ntx;
+            bz = r % g.ntz;
+            const uint32_t yb = r / g.ntz;
+            by = xcd * band + yb;
+            return yb < band && by < g.nty;
         }
         if(g.order == 5u)
         {
@@ -456,13 +491,13 @@ namespace
                     update(acc[i], mm + i);
 #pragma unroll
                 for(int i = 0; i < UNROLL; ++i)
-                    store_voxels<VX, NT>(vp + (mm + i) * slice, acc[i]);
+                    store_voxels<VX, NT>(vp + (mm + i) * slice, acc[i], g.store_sc1 != 0u);
             }
             for(; mm < mcount; ++mm)
             {
                 vec_t acc = load_voxels<VX, NT>(vp + mm * slice);
                 update(acc, mm);
-                store_voxels<VX, NT>(vp + mm * slice, acc);
+                store_voxels<VX, NT>(vp + mm * slice, acc, g.store_sc1 != 0u);
             }
         };
         if(all_fast)
@@ -477,8 +512,10 @@ namespace
     // stream has the shape of the fastest plain sweep (tools/membench6.hip: 6.0 TB/s against 5.5 for the z-walk).
     // The z-invariant column state that the tile kernel keeps in registers is computed once per workgroup (one
     // thread per column) and shared through LDS as structure-of-arrays, read back as float4 per 4 columns.
-    // Needs dim_x % 4 == 0 and a 16-byte aligned volume. LDS: 7 * 64 * 4*RPL floats of column state + the box.
+    // Needs dim_x % 4 == 0 and a 16-byte aligned volume. LDS: 8 * 64 * 4*RPL words of column state + the box.
     // --------------------------------------------------------------------------------------------
+    constexpr uint32_t SLICE_STATE_ARRAYS = 8u;
+
     template <int NW, int RPL, bool NT, bool FD>
     __global__ void __launch_bounds__(NW * 64, 8) bp_slice_kernel(const BpParams g)
     {
@@ -492,7 +529,8 @@ namespace
         float* c_ymax = lds + 4u * NCOL;
         int* c_xoff = reinterpret_cast<int*>(lds + 5u * NCOL);
         int* c_x1i = reinterpret_cast<int*>(lds + 6u * NCOL);
-        float* lds_box = lds + 7u * NCOL;
+        int* c_fast = reinterpret_cast<int*>(lds + 7u * NCOL);
+        float* lds_box = lds + SLICE_STATE_ARRAYS * NCOL;
 
         const uint32_t tid = threadIdx.x;
         const uint32_t lane = tid & 63u;
@@ -508,14 +546,16 @@ namespace
         const uint32_t l1 = min(l0 + TY - 1u, g.v_dim_y - 1u);
         const uint32_t m1 = min(m0 + NW - 1u, g.v_dim_z - 1u);
 
-        const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats - 7u * NCOL);
+        const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats - SLICE_STATE_ARRAYS * NCOL);
         stage_box(g, box, lds_box, wave, NW, lane);
 
         // column state: thread t computes columns t, t + NW*64, ...; column c = cy * 64 + cx
+        const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
+        const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
         for(uint32_t c = tid; c < NCOL; c += NW * 64u)
         {
             const uint32_t cx = c & 63u, cy = c >> 6;
-            const Column col = make_column<FD>(g, box, g.k_off + min(k0 + cx, k1), g.l_off + min(l0 + cy, l1), 0.f, 0.f);
+            const Column col = make_column<FD>(g, box, g.k_off + min(k0 + cx, k1), g.l_off + min(l0 + cy, l1), z_first, z_last);
             c_factor[c] = col.factor;
             c_u[c] = col.u;
             c_wx1[c] = col.wx1;
@@ -523,6 +563,7 @@ namespace
             c_ymax[c] = col.ymax;
             c_xoff[c] = col.xoff;
             c_x1i[c] = col.x1i;
+            c_fast[c] = col.fast ? 1 : 0;
         }
         __syncthreads();
 
@@ -538,28 +579,40 @@ namespace
         const size_t row4 = static_cast<size_t>(4u) * g.v_dim_x;
 
         float4 acc[RPL];
+        bool all_fast = true;
 #pragma unroll
         for(int r = 0; r < RPL; ++r)
             if(l0 + yy + 4u * r < g.v_dim_y)
+            {
                 acc[r] = load_voxels<4, NT>(vp + r * row4);
+                const int4 f = *reinterpret_cast<const int4*>(c_fast + (yy + 4u * r) * 64u + xq * 4u);
+                all_fast = all_fast && ((f.x & f.y & f.z & f.w) != 0);
+            }
+        auto add = [&](auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-        for(int r = 0; r < RPL; ++r)
-        {
-            if(l0 + yy + 4u * r >= g.v_dim_y)
-                continue;
-            const uint32_t c = (yy + 4u * r) * 64u + xq * 4u;
-            const float4 f4 = *reinterpret_cast<const float4*>(c_factor + c);
-            const float4 u4 = *reinterpret_cast<const float4*>(c_u + c);
-            const float4 a4 = *reinterpret_cast<const float4*>(c_wx1 + c);
-            const float4 b4 = *reinterpret_cast<const float4*>(c_wx2 + c);
-            const float4 y4 = *reinterpret_cast<const float4*>(c_ymax + c);
-            const int4 o4 = *reinterpret_cast<const int4*>(c_xoff + c);
-            const int4 i4 = *reinterpret_cast<const int4*>(c_x1i + c);
-            acc[r].x += voxel_contribution<FD, false>(g, box, lds_box, z_m, Column{f4.x, u4.x, a4.x, b4.x, y4.x, o4.x, i4.x, false});
-            acc[r].y += voxel_contribution<FD, false>(g, box, lds_box, z_m, Column{f4.y, u4.y, a4.y, b4.y, y4.y, o4.y, i4.y, false});
-            acc[r].z += voxel_contribution<FD, false>(g, box, lds_box, z_m, Column{f4.z, u4.z, a4.z, b4.z, y4.z, o4.z, i4.z, false});
-            acc[r].w += voxel_contribution<FD, false>(g, box, lds_box, z_m, Column{f4.w, u4.w, a4.w, b4.w, y4.w, o4.w, i4.w, false});
-        }
+            for(int r = 0; r < RPL; ++r)
+            {
+                if(l0 + yy + 4u * r >= g.v_dim_y)
+                    continue;
+                const uint32_t c = (yy + 4u * r) * 64u + xq * 4u;
+                const float4 f4 = *reinterpret_cast<const float4*>(c_factor + c);
+                const float4 u4 = *reinterpret_cast<const float4*>(c_u + c);
+                const float4 a4 = *reinterpret_cast<const float4*>(c_wx1 + c);
+                const float4 b4 = *reinterpret_cast<const float4*>(c_wx2 + c);
+                const float4 y4 = *reinterpret_cast<const float4*>(c_ymax + c);
+                const int4 o4 = *reinterpret_cast<const int4*>(c_xoff + c);
+                const int4 i4 = *reinterpret_cast<const int4*>(c_x1i + c);
+                acc[r].x += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.x, u4.x, a4.x, b4.x, y4.x, o4.x, i4.x, FAST});
+                acc[r].y += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.y, u4.y, a4.y, b4.y, y4.y, o4.y, i4.y, FAST});
+                acc[r].z += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.z, u4.z, a4.z, b4.z, y4.z, o4.z, i4.z, FAST});
+                acc[r].w += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.w, u4.w, a4.w, b4.w, y4.w, o4.w, i4.w, FAST});
+            }
+        };
+        if(all_fast)
+            add(std::true_type{});
+        else
+            add(std::false_type{});
 #pragma unroll
         for(int r = 0; r < RPL; ++r)
             if(l0 + yy + 4u * r < g.v_dim_y)
@@ -724,9 +777,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + TY - 1u) / TY;
         g.ntz = (g.v_dim_z + g.tz - 1u) / g.tz;
-        uint32_t blocks = g.ntx * g.nty * g.ntz;
-        if(g.order == 5u)
-            blocks = ((blocks + 7u) / 8u) * 8u;
+        uint32_t blocks = grid_blocks(g);
         hipLaunchKernelGGL((bp_tile_kernel<VX, UNROLL, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, g);
     }
 
@@ -759,15 +810,13 @@ namespace
     int launch_slice(BpParams& g, uint32_t box_bytes, hipStream_t stream)
     {
         constexpr uint32_t TY = 4u * RPL;
-        constexpr uint32_t state_floats = 7u * 64u * TY;
+        constexpr uint32_t state_floats = SLICE_STATE_ARRAYS * 64u * TY;
         g.tz = NW;
         g.lds_floats = state_floats + box_bytes / sizeof(float);
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + TY - 1u) / TY;
         g.ntz = (g.v_dim_z + NW - 1u) / NW;
-        uint32_t blocks = g.ntx * g.nty * g.ntz;
-        if(g.order == 5u)
-            blocks = ((blocks + 7u) / 8u) * 8u;
+        uint32_t blocks = grid_blocks(g);
         const uint32_t lds_bytes = g.lds_floats * sizeof(float);
         if(lds_bytes > 64u * 1024u)
         {
@@ -814,9 +863,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + 15u) / 16u;
         g.ntz = (g.v_dim_z + TZ - 1u) / TZ;
-        uint32_t blocks = g.ntx * g.nty * g.ntz;
-        if(g.order == 5u)
-            blocks = ((blocks + 7u) / 8u) * 8u;
+        uint32_t blocks = grid_blocks(g);
         hipLaunchKernelGGL((bp_fused_kernel<TZ, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, fp);
     }
 
@@ -925,6 +972,7 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
     g.tz = tz;
     g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : 5u;
+    g.store_sc1 = ctx->bp_nt == 2 ? 1u : 0u;
     return PARIS_HIP_SUCCESS;
 }
 
@@ -967,7 +1015,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         int vx = lane_width(d_v, v_dim_x); // unless the tuning knob asks for less
         if(ctx->bp_vx && ctx->bp_vx < vx)
             vx = ctx->bp_vx;
-        const int unroll = ctx->bp_unroll ? ctx->bp_unroll : 2;
+        const int unroll = ctx->bp_unroll ? ctx->bp_unroll : 1; // interleaved A/B on 2048^3 (tools/ab_bp.py): 1 beats 2 by ~3 %
         const bool nt = ctx->bp_nt != 0;
         const bool want_slice = ctx->bp_variant == 3; // measured slower than the tile kernel so far: opt-in only
         if(want_slice && vx == 4)
@@ -1132,10 +1180,10 @@ extern "C" int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant
 
 extern "C" int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, int nontemporal)
 {
-    if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5) || nontemporal < -1 || nontemporal > 1)
+    if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5 || order == 8) || nontemporal < -1 || nontemporal > 2)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_order = order;
-    ctx->bp_nt = nontemporal < 0 ? 1 : nontemporal;
+    ctx->bp_nt = nontemporal < 0 ? 2 : nontemporal;
     return PARIS_HIP_SUCCESS;
 }
 

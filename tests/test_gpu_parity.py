@@ -290,7 +290,7 @@ def test_backproject_slice_kernel_shapes_bit_exact(be, oracle, shape, lds_bytes)
     be.set_backproject_slice_shape(*shape)
     be.set_backproject_tuning(lds_bytes=lds_bytes)
     try:
-        for order in (0, 1, 5):
+        for order in (0, 1, 5, 8):
             be.set_backproject_order(order, 1)
             got = hip_backproject_all(be, projs, det, vg, dims)
             assert_bit_equal(got, want)

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of backprojection kernel configurations on the full 2048^3 volume (or --slices N): R rounds over all
+configurations, median per configuration (guide rule: perf deltas come from interleaved rounds in one process)."""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from paris_amd import backend as B  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--slices", type=int, default=2048)
+ap.add_argument("--rounds", type=int, default=4)
+ap.add_argument("--configs", default="5:16:2:2,8:16:2:2,8:8:1:2,8:16:1:2", help="order:tz:unroll:nt[,...]")
+args = ap.parse_args()
+n = 2048
+det = B.DetectorGeometry(n, n, 0.2, 0.2, 0, 0, 500, 500, 0.25)
+nat = B.calculate_volume_geometry(det)
+vg = B.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
+be = B.Backend(0, synchronous=False)
+d_p = B.load(be, B.Projection(np.random.default_rng(1).random((n, n), dtype=np.float32), n, n))
+d_v = be.make_volume_device(n, n, args.slices)
+z_first = (n - args.slices) // 2
+cfgs = [tuple(int(x) for x in c.split(":")) for c in args.configs.split(",")]
+ms = {c: [] for c in cfgs}
+angles = (0, 45, 100, 200, 300)
+for rnd in range(args.rounds + 1):
+    for c in cfgs:
+        order, tz, un, nt = c
+        be.set_backproject_tuning(4, un, tz, 0)
+        be.set_backproject_order(order, nt)
+        for a in angles:
+            d_p.idx = a * 4
+            B.backproject(be, d_p, d_v, z_first, det, vg, False, False, None)
+            t = be.last_backproject_ms()
+            if rnd:
+                ms[c].append(t)
+vox = float(n) * n * args.slices
+for c in cfgs:
+    med = statistics.median(ms[c])
+    print(json.dumps(dict(order=c[0], tz=c[1], unroll=c[2], nt=c[3], median_ms=med, min_ms=min(ms[c]), max_ms=max(ms[c]),
+                          gbs=8 * vox / med / 1e6, frac=8 * vox / med / 1e6 / 8000)))
