@@ -236,7 +236,7 @@ int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* ms, uint32_t
  * paris_hip_backproject_batch uses its fused kernel under variant 0 and runs one launch per projection otherwise. */
 int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant);
 /* Tuning knobs of the LDS-staged kernel; 0 keeps the default. vx: voxels per lane along x (1, 2, 4; capped by
- * the volume's alignment), unroll: z slices in flight per lane (1, 2, 4), tz: slices per tile, lds_bytes: LDS
+ * the volume's alignment), unroll: z slices in flight per lane (1, 2, 4; 3 = one at a time with the next one prefetched), tz: slices per tile, lds_bytes: LDS
  * budget per workgroup for the staged detector box (1024..65536). Results do not depend on any of them. */
 int paris_hip_set_backproject_tuning(paris_hip_ctx* ctx, int vx, int unroll, int tz, int lds_bytes);
 /* Shape of the slice kernel: waves (= slices per tile) x row groups per lane; (16,4) (16,2) (8,4) (8,2) (8,1),

@@ -479,25 +479,43 @@ namespace
                 for(int j = 0; j < VX; ++j)
                     elem<VX>(acc, j) += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[j]);
             };
-            uint32_t mm = 0;
-            for(; mm + UNROLL <= mcount; mm += UNROLL)
+            if constexpr(UNROLL == 3)
             {
-                vec_t acc[UNROLL];
-#pragma unroll
-                for(int i = 0; i < UNROLL; ++i)
-                    acc[i] = load_voxels<VX, NT>(vp + (mm + i) * slice);
-#pragma unroll
-                for(int i = 0; i < UNROLL; ++i)
-                    update(acc[i], mm + i);
-#pragma unroll
-                for(int i = 0; i < UNROLL; ++i)
-                    store_voxels<VX, NT>(vp + (mm + i) * slice, acc[i], g.store_sc1 != 0u);
+                // one slice at a time, with the next slice's load issued before the current one is updated and stored:
+                // two loads in flight per lane for 4 extra registers instead of a second unrolled body
+                vec_t cur = load_voxels<VX, NT>(vp);
+                for(uint32_t mm = 0; mm < mcount; ++mm)
+                {
+                    vec_t nxt = cur;
+                    if(mm + 1u < mcount)
+                        nxt = load_voxels<VX, NT>(vp + (mm + 1u) * slice);
+                    update(cur, mm);
+                    store_voxels<VX, NT>(vp + mm * slice, cur, g.store_sc1 != 0u);
+                    cur = nxt;
+                }
             }
-            for(; mm < mcount; ++mm)
+            else
             {
-                vec_t acc = load_voxels<VX, NT>(vp + mm * slice);
-                update(acc, mm);
-                store_voxels<VX, NT>(vp + mm * slice, acc, g.store_sc1 != 0u);
+                uint32_t mm = 0;
+                for(; mm + UNROLL <= mcount; mm += UNROLL)
+                {
+                    vec_t acc[UNROLL];
+#pragma unroll
+                    for(int i = 0; i < UNROLL; ++i)
+                        acc[i] = load_voxels<VX, NT>(vp + (mm + i) * slice);
+#pragma unroll
+                    for(int i = 0; i < UNROLL; ++i)
+                        update(acc[i], mm + i);
+#pragma unroll
+                    for(int i = 0; i < UNROLL; ++i)
+                        store_voxels<VX, NT>(vp + (mm + i) * slice, acc[i], g.store_sc1 != 0u);
+                }
+                for(; mm < mcount; ++mm)
+                {
+                    vec_t acc = load_voxels<VX, NT>(vp + mm * slice);
+                    update(acc, mm);
+                    store_voxels<VX, NT>(vp + mm * slice, acc, g.store_sc1 != 0u);
+                }
             }
         };
         if(all_fast)
@@ -788,6 +806,7 @@ namespace
         {
             case 1: launch_tile<VX, 1, NT, FD>(g, stream); break;
             case 2: launch_tile<VX, 2, NT, FD>(g, stream); break;
+            case 3: launch_tile<VX, 3, NT, FD>(g, stream); break; // 1 + prefetch of the next slice
             default: launch_tile<VX, 4, NT, FD>(g, stream); break;
         }
     }
@@ -1225,7 +1244,7 @@ extern "C" int paris_hip_set_backproject_tuning(paris_hip_ctx* ctx, int vx, int 
 {
     if(ctx == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    if(!(vx == 0 || vx == 1 || vx == 2 || vx == 4) || !(unroll == 0 || unroll == 1 || unroll == 2 || unroll == 4))
+    if(!(vx == 0 || vx == 1 || vx == 2 || vx == 4) || !(unroll == 0 || unroll == 1 || unroll == 2 || unroll == 3 || unroll == 4))
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(tz < 0 || tz > 4096 || lds_bytes < 0 || lds_bytes > static_cast<int>(LDS_BYTES_MAX)
        || (lds_bytes != 0 && lds_bytes < 1024))
