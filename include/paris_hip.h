@@ -252,6 +252,9 @@ int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, int nontempor
  * found the detector coordinate v = x / pitch - 0.5 identical (bit for bit, or out of any detector's range both ways).
  * enable = 0 forces the IEEE sequence. Results never depend on this. */
 int paris_hip_set_backproject_fast_division(paris_hip_ctx* ctx, int enable);
+/* Staging of the detector box into LDS 4 pixels per lane (default on; used when the projection base and pitch are
+ * 16-byte aligned, 8-byte for half pixels). enable = 0 forces one pixel per lane. Results never depend on this. */
+int paris_hip_set_backproject_vector_staging(paris_hip_ctx* ctx, int enable);
 /* Runs (or looks up) the exhaustive check for one divisor: *exact = 1 when multiply + 2 FMA reproduces
  * x / divisor - 0.5 for every fp32 x (see above). */
 int paris_hip_fast_division_is_exact(paris_hip_ctx* ctx, float divisor, int* exact);

@@ -109,6 +109,7 @@ SIGNATURES = {
     "paris_hip_set_backproject_order": (C.c_int, [_vp, C.c_int, C.c_int]),
     "paris_hip_set_backproject_slice_shape": (C.c_int, [_vp, C.c_int, C.c_int]),
     "paris_hip_set_backproject_fast_division": (C.c_int, [_vp, C.c_int]),
+    "paris_hip_set_backproject_vector_staging": (C.c_int, [_vp, C.c_int]),
     "paris_hip_fast_division_is_exact": (C.c_int, [_vp, _f, _P(C.c_int)]),
 }
 

@@ -268,6 +268,10 @@ class Backend:
         check(self._L.paris_hip_fast_division_is_exact(self._ctx, divisor, C.byref(ok)), "paris_hip_fast_division_is_exact")
         return bool(ok.value)
 
+    def set_backproject_vector_staging(self, enable=True):
+        check(self._L.paris_hip_set_backproject_vector_staging(self._ctx, int(bool(enable))),
+              "paris_hip_set_backproject_vector_staging")
+
     def set_backproject_fast_division(self, enable=True):
         check(self._L.paris_hip_set_backproject_fast_division(self._ctx, int(bool(enable))),
               "paris_hip_set_backproject_fast_division")

@@ -47,6 +47,7 @@ namespace
         uint32_t ntx, nty, ntz; // tiles per axis
         uint32_t order;         // workgroup -> tile mapping, see tile_of_block
         uint32_t store_sc1;     // nontemporal stores also carry sc1 (write-through)
+        uint32_t stage_vec4;    // detector rows may be staged 4 pixels at a time (base and pitch aligned)
     };
 
     struct ColConst
@@ -283,7 +284,17 @@ namespace
             b.bw = 0;
             bh = 0;
         }
-        b.stride = b.bw | 1;
+        if(g.stage_vec4 && b.bw > 0)
+        {
+            // 4-pixel staging: start on a multiple of 4 and cover whole groups of 4. Columns past p_dim_x (< pitch,
+            // which is a multiple of 4 here) are readable padding that no valid tap addresses.
+            const int end = min((bx1 + 4) & ~3, static_cast<int>(g.p_pitch));
+            b.bx0 &= ~3;
+            b.bw = end - b.bx0;
+            b.stride = b.bw + 4; // multiple of 4: 16-byte aligned rows for ds_write_b128, not a power of two
+        }
+        else
+            b.stride = b.bw | 1;
         b.bhs = min(bh, static_cast<int>(box_floats) / b.stride); // rows that fit the LDS budget
         if(b.bhs < 2)
         {
@@ -303,10 +314,41 @@ namespace
         return static_cast<const volatile float*>(g.proj)[idx];
     }
 
-    // global -> LDS: one wave per detector row, lanes along the row (coalesced)
+    // global -> LDS. Aligned projections (stage_vec4) move 4 pixels per lane and instruction (16 B fp32 / 8 B half),
+    // several short rows per wave-instruction; otherwise one wave per detector row, one pixel per lane.
     __device__ __forceinline__ void stage_box(const BpParams& g, const Box& b, float* lds_box, uint32_t wave,
                                               uint32_t n_waves, uint32_t lane)
     {
+        if(g.stage_vec4)
+        {
+            const uint32_t n4 = static_cast<uint32_t>(b.bw) >> 2; // groups of 4 per row
+            if(n4 == 0u)
+                return;
+            const uint32_t rows_per_pass = n4 <= 64u ? 64u / n4 : 1u; // rows one wave-instruction covers
+            const uint32_t lr = n4 <= 64u ? lane / n4 : 0u;
+            const uint32_t lc = n4 <= 64u ? lane - lr * n4 : lane;
+            if(lr >= rows_per_pass)
+                return; // lanes beyond the last whole row of the pass idle
+            for(uint32_t r = wave * rows_per_pass + lr; r < static_cast<uint32_t>(b.bhs); r += n_waves * rows_per_pass)
+            {
+                const size_t row = static_cast<size_t>(b.by0 + static_cast<int>(r)) * g.p_pitch + static_cast<size_t>(b.bx0);
+                float* dst = lds_box + r * static_cast<uint32_t>(b.stride);
+                for(uint32_t c4 = lc; c4 < n4; c4 += 64u)
+                {
+                    float4 v;
+                    if(g.proj_f16)
+                    {
+                        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                        const half4 h = *reinterpret_cast<const half4*>(static_cast<const _Float16*>(g.proj) + row + 4u * c4);
+                        v = make_float4(static_cast<float>(h.x), static_cast<float>(h.y), static_cast<float>(h.z), static_cast<float>(h.w));
+                    }
+                    else
+                        v = *reinterpret_cast<const float4*>(static_cast<const float*>(g.proj) + row + 4u * c4);
+                    *reinterpret_cast<float4*>(dst + 4u * c4) = v;
+                }
+            }
+            return;
+        }
         if(g.proj_f16)
         {
             // fp16 projection storage (BASELINE config 5): widened to fp32 here, all arithmetic stays fp32
@@ -990,8 +1032,12 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     g.p_dim_y_f = static_cast<float>(p_dim_y);
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
     g.tz = tz;
-    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : 5u;
+    // default mapping: a band of y tiles per XCD when the bands are thick enough to keep every XCD busy (volumes of
+    // >= 1024 rows), else a contiguous run of tiles per XCD
+    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : ((v_dim_y + 15u) / 16u >= 64u ? 8u : 5u);
     g.store_sc1 = ctx->bp_nt == 2 ? 1u : 0u;
+    // 4-pixel staging needs every detector row to start 16-byte (half: 8-byte) aligned
+    g.stage_vec4 = (ctx->bp_stage_vec4 != 0 && g.p_pitch % 4u == 0 && reinterpret_cast<uintptr_t>(d_p) % (4u * px) == 0) ? 1u : 0u;
     return PARIS_HIP_SUCCESS;
 }
 
@@ -1034,7 +1080,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         int vx = lane_width(d_v, v_dim_x); // unless the tuning knob asks for less
         if(ctx->bp_vx && ctx->bp_vx < vx)
             vx = ctx->bp_vx;
-        const int unroll = ctx->bp_unroll ? ctx->bp_unroll : 1; // interleaved A/B on 2048^3 (tools/ab_bp.py): 1 beats 2 by ~3 %
+        const int unroll = ctx->bp_unroll ? ctx->bp_unroll : 2; // interleaved A/B on 2048^3 (tools/ab_bp.py, profiles/)
         const bool nt = ctx->bp_nt != 0;
         const bool want_slice = ctx->bp_variant == 3; // measured slower than the tile kernel so far: opt-in only
         if(want_slice && vx == 4)
@@ -1216,6 +1262,14 @@ extern "C" int paris_hip_fast_division_is_exact(paris_hip_ctx* ctx, float diviso
     if(int rc = fastdiv_is_exact(ctx, divisor, &ok))
         return rc;
     *exact = ok ? 1 : 0;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_set_backproject_vector_staging(paris_hip_ctx* ctx, int enable)
+{
+    if(ctx == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    ctx->bp_stage_vec4 = enable ? 1 : 0;
     return PARIS_HIP_SUCCESS;
 }
 

@@ -248,17 +248,41 @@ def test_backproject_every_kernel_shape_bit_exact(be, oracle, tuning):
 
 
 @pytest.mark.parametrize("fast", [False, True])
-def test_backproject_fast_division_switch(be, oracle, kat_golden, fast):
-    """The multiply + 2 FMA division by the pixel pitch (used only after the exhaustive per-divisor check) and the
-    IEEE sequence give the same bits."""
+@pytest.mark.parametrize("vec", [False, True])
+def test_backproject_fast_division_and_staging_switches(be, oracle, kat_golden, fast, vec):
+    """The multiply + 2 FMA division by the pixel pitch (used only after the exhaustive per-divisor check) vs the IEEE
+    sequence, and 4-pixel vs 1-pixel staging of the detector box: same bits."""
     det = B.DetectorGeometry(*KAT)
     vg = B.calculate_volume_geometry(det)
     be.set_backproject_fast_division(fast)
+    be.set_backproject_vector_staging(vec)
     try:
         got = hip_backproject_all(be, kat_golden["filtered"], det, vg, (61, 67, 67))
+        roi = B.RegionOfInterest(8, 40, 4, 36, 10, 30)
+        rv = hip_backproject_all(be, kat_golden["filtered"], det, vg, (20, 32, 32), roi=roi)  # 16-byte lanes
     finally:
         be.set_backproject_fast_division(True)
+        be.set_backproject_vector_staging(True)
     assert_bit_equal(got, kat_golden["volume"])
+    assert_bit_equal(rv, kat_golden["volume"][10:30, 4:36, 8:40])
+
+
+def test_backproject_unaligned_projection_pitch(be, oracle, kat_golden):
+    """A projection whose rows are not 16-byte aligned (pitch = 65 floats) takes the 1-pixel staging path."""
+    det = B.DetectorGeometry(*KAT)
+    vg = B.calculate_volume_geometry(det)
+    d_v = be.make_volume_device(67, 67, 61)
+    raw = be.make_projection_device(65, 48)  # 65-float rows requested; use a 65-float pitch inside its buffer
+    for i in range(8):
+        padded = np.zeros((48, 65), np.float32)
+        padded[:, :64] = kat_golden["filtered"][i]
+        _lib.check(_lib.load().paris_hip_memcpy_volume_h2d(be._ctx, raw.ptr, padded.ctypes.data, 65, 48, 1), "h2d")
+        be.synchronize()
+        p = be.wrap_projection(raw.ptr, 65 * 4, 64, 48, idx=i)
+        B.backproject(be, p, d_v, 0, det, vg, False, False, None)
+    assert_bit_equal(volume_to_host(be, d_v), kat_golden["volume"])
+    be.free(d_v)
+    be.free(raw)
 
 
 def test_fast_division_exhaustive_check(be):
