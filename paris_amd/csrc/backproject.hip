@@ -487,15 +487,13 @@ namespace
 
         const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats);
         stage_box(g, box, lds, wave, 4u, lane);
-        __syncthreads();
 
         // ---- per-lane columns --------------------------------------------------------------------
         const uint32_t xq = lane % XL;
         const uint32_t yy = lane / XL;
         const uint32_t k = k0 + xq * VX;
         const uint32_t l = l0 + wave * RW + yy;
-        if(k >= g.v_dim_x || l >= g.v_dim_y)
-            return;
+        const bool active = k < g.v_dim_x && l < g.v_dim_y;
 
         const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
         const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
@@ -504,9 +502,14 @@ namespace
 #pragma unroll
         for(int j = 0; j < VX; ++j)
         {
-            col[j] = make_column<FD>(g, box, g.k_off + k + j, g.l_off + l, z_first, z_last);
+            col[j] = make_column<FD>(g, box, g.k_off + min(k + j, k1), g.l_off + min(l, l1), z_first, z_last);
             all_fast = all_fast && col[j].fast;
         }
+
+        // (keeping the box loads in flight across this setup was measured slower: profiles/r01_ab_full_volume_6.jsonl)
+        __syncthreads();
+        if(!active)
+            return;
 
         using vec_t = typename vec_of<VX>::type;
         const size_t slice = static_cast<size_t>(g.v_dim_x) * g.v_dim_y;
@@ -1037,7 +1040,8 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : ((v_dim_y + 15u) / 16u >= 64u ? 8u : 5u);
     g.store_sc1 = ctx->bp_nt == 2 ? 1u : 0u;
     // 4-pixel staging needs every detector row to start 16-byte (half: 8-byte) aligned
-    g.stage_vec4 = (ctx->bp_stage_vec4 != 0 && g.p_pitch % 4u == 0 && reinterpret_cast<uintptr_t>(d_p) % (4u * px) == 0) ? 1u : 0u;
+    g.stage_vec4 = (ctx->bp_stage_vec4 != 0 && g.p_pitch % 4u == 0 && reinterpret_cast<uintptr_t>(d_p) % (4u * px) == 0)
+                       ? 1u : 0u;
     return PARIS_HIP_SUCCESS;
 }
 
