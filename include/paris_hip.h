@@ -152,6 +152,10 @@ int paris_hip_make_filter(paris_hip_ctx* ctx, uint32_t size, float tau, float** 
 int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
                            const float* d_k, uint32_t filter_size, uint32_t n_col);
 
+/* Row-filter kernel: 0 = default (radix-16 register passes for filter_size >= 1024, radix-2 below), 1 = the radix-2
+ * kernel for every size (cross-check). Same transform; results differ by fp32 rounding only. */
+int paris_hip_set_filter_variant(paris_hip_ctx* ctx, int variant);
+
 /* ---- backprojection: backend::backproject (src/openmp/backprojection.cpp:156-199,
  *      src/cuda/backprojection.cu:133-243) ---------------------------------------------------------- */
 /* Adds one filtered projection into the (sub)volume d_v of v_dim_x*v_dim_y*v_dim_z voxels whose first

@@ -80,6 +80,7 @@ SIGNATURES = {
     "paris_hip_weight": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _f, _f, _f, _f, _f]),
     "paris_hip_make_filter": (C.c_int, [_vp, _u32, _f, _P(_vp)]),
     "paris_hip_apply_filter": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _u32, _u32]),
+    "paris_hip_set_filter_variant": (C.c_int, [_vp, C.c_int]),
     "paris_hip_backproject": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _u32, _u32, _u32, _u32,
                                         _P(DetectorGeometry), _P(VolumeGeometry), C.c_int,
                                         _P(RegionOfInterest), _f, _f, _f, _f]),

@@ -202,6 +202,9 @@ class Backend:
         check(self._L.paris_hip_apply_filter(self._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, k.ptr, filter_size,
                                              n_col), "paris_hip_apply_filter")
 
+    def set_filter_variant(self, variant):
+        check(self._L.paris_hip_set_filter_variant(self._ctx, variant), "paris_hip_set_filter_variant")
+
     def backproject(self, p, v, v_offset, det_geo, vol_geo, enable_roi, roi, sin, cos, delta_s, delta_t):
         """backend::backproject (src/openmp/backprojection.cpp:156-199)"""
         r = roi if roi is not None else RegionOfInterest()

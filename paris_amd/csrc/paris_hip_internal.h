@@ -48,6 +48,8 @@ struct paris_hip_ctx
     int bp_fastdiv = 1; // use the validated multiply+2 FMA division by the pixel pitch when it is exact
     std::map<uint32_t, bool> fastdiv_exact; // divisor bits -> exhaustive check result
     bool filter_lds_attr_set = false;
+    bool filter_r16_attr_set[5] = {false, false, false, false, false}; // LOG2N 10..14
+    int filter_variant = 0; // 0: radix-16 register passes for N >= 1024, 1: radix-2 kernel for every N
     std::map<uint32_t, paris_hip_fft_plan> plans; // keyed by FFT length
     // K cached by paris_hip_stage_filter (reference: thread_local static in src/filtering.cpp:42)
     float* stage_k = nullptr;

@@ -112,8 +112,9 @@ def test_make_filter_golden(be, kat_golden):
         be.free(k)
 
 
-@pytest.mark.parametrize("n_row,n_col", [(64, 48), (512, 37), (1000, 8), (5, 3), (2048, 6), (4097, 2)])
-def test_apply_filter(be, oracle, n_row, n_col):
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("n_row,n_col", [(64, 48), (512, 37), (1000, 8), (5, 3), (2048, 6), (4097, 2), (3000, 5), (8192, 3)])
+def test_apply_filter(be, oracle, n_row, n_col, variant):
     fs = oracle.filter_size(n_row)
     assert B.filter_size(n_row) == fs
     tau = 0.2
@@ -121,7 +122,11 @@ def test_apply_filter(be, oracle, n_row, n_col):
     want = oracle.apply_filter(p.copy(), oracle.make_filter(fs, tau), fs)
     d_p = to_device(be, p)
     k = be.make_filter(fs, tau)
-    be.apply_filter(d_p, k, fs, n_col)
+    be.set_filter_variant(variant)  # 0: radix-16 register passes (N >= 1024), 1: radix-2 in LDS
+    try:
+        be.apply_filter(d_p, k, fs, n_col)
+    finally:
+        be.set_filter_variant(0)
     got = to_host(be, d_p)
     assert np.max(np.abs(got - want)) <= FILTER_TOL * np.abs(want).max()
     assert rel_l2(got, want) <= FILTER_TOL

@@ -15,7 +15,7 @@ from paris_amd import backend as B  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--slices", type=int, default=2048)
 ap.add_argument("--rounds", type=int, default=4)
-ap.add_argument("--configs", default="5:16:1:2:1,5:16:1:2:0", help="order:tz:unroll:nt:vec4[,...]")
+ap.add_argument("--configs", default="8:16:2:2:1", help="order:tz:unroll:nt:vec4[:vx[:lds_bytes]][,...]")
 args = ap.parse_args()
 n = 2048
 det = B.DetectorGeometry(n, n, 0.2, 0.2, 0, 0, 500, 500, 0.25)
@@ -30,9 +30,11 @@ ms = {c: [] for c in cfgs}
 angles = (0, 45, 100, 200, 300)
 for rnd in range(args.rounds + 1):
     for c in cfgs:
-        order, tz, un, nt, vec = c
+        order, tz, un, nt, vec = c[:5]
+        vx = c[5] if len(c) > 5 else 4
+        lds = c[6] if len(c) > 6 else 0
         be.set_backproject_vector_staging(vec)
-        be.set_backproject_tuning(4, un, tz, 0)
+        be.set_backproject_tuning(vx, un, tz, lds)
         be.set_backproject_order(order, nt)
         for a in angles:
             d_p.idx = a * 4
@@ -43,5 +45,5 @@ for rnd in range(args.rounds + 1):
 vox = float(n) * n * args.slices
 for c in cfgs:
     med = statistics.median(ms[c])
-    print(json.dumps(dict(order=c[0], tz=c[1], unroll=c[2], nt=c[3], vec4=c[4], median_ms=med, min_ms=min(ms[c]), max_ms=max(ms[c]),
+    print(json.dumps(dict(cfg=":".join(str(x) for x in c), median_ms=med, min_ms=min(ms[c]), max_ms=max(ms[c]),
                           gbs=8 * vox / med / 1e6, frac=8 * vox / med / 1e6 / 8000)))
