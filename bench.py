@@ -70,35 +70,13 @@ def measured_traffic(w, world):
     return best if best else (None, None)
 
 
-def usable_cores():
-    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0))
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            with open(path) as f:
-                parts = f.read().split()
-            if path.endswith("cpu.max"):
-                if parts[0] != "max":
-                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
-            else:
-                quota = int(parts[0])
-                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
-                    period = int(f.read().split()[0])
-                if quota > 0:
-                    n = min(n, max(1, int(quota / period + 0.5)))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return n
-
-
 def cpu_baseline(w, budget_s):
     """Times the oracle's backprojection on this host's cores: the workload's geometry, a slab of `slices`
     central slices, as many projections as fit the time budget."""
     import numpy as np
 
     from oracle import oracle as O
-    cores = usable_cores()
+    cores = O.usable_cores()
     O.lib().po_set_num_threads(cores)
     det = O.DetectorGeometry(w["n_row"], w["n_col"], 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 360.0 / w["n_proj"])
     nat = O.calculate_volume_geometry(det)

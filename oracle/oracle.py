@@ -45,6 +45,29 @@ _lib = None
 _fp = C.POINTER(C.c_float)
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box shows
+    256 logical CPUs but grants a 16-core quota; OpenMP's default of one thread per visible CPU then thrashes)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read().split()[0])
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -72,6 +95,7 @@ def lib():
         L.po_lcg_fill.argtypes = [_fp, C.c_size_t, C.c_uint32]
         L.po_num_threads.restype = C.c_int
         L.po_set_num_threads.argtypes = [C.c_int]
+        L.po_set_num_threads(usable_cores())
         _lib = L
     return _lib
 
