@@ -41,6 +41,7 @@ namespace
         float min_h, min_v; // -(p_dim * l_px/2) - delta
         float l_px_x, l_px_y;
         float rcp_l_px_y; // RN(1 / l_px_y), used only by the validated fast division
+        float rcp_l_px_x;
         float p_dim_x_f, p_dim_y_f;
         uint32_t lds_floats;
         uint32_t tz; // slices per tile
@@ -55,21 +56,6 @@ namespace
         float factor, h, u;
     };
 
-    // src/openmp/backprojection.cpp:116-129,139 for one (x,y) column; K, L are global voxel indices
-    __device__ __forceinline__ ColConst column_constants(const BpParams& g, uint32_t K, uint32_t L)
-    {
-        const float x_k = g.x_base + static_cast<float>(K) * g.l_vx_x; // :39-43
-        const float y_l = g.y_base + static_cast<float>(L) * g.l_vx_y;
-        const float s = x_k * g.cos_phi + y_l * g.sin_phi;  // :121
-        const float t = -x_k * g.sin_phi + y_l * g.cos_phi; // :122
-        const float den = s + g.d_so;
-        ColConst c;
-        c.factor = g.d_sd / den;                                      // :125
-        c.h = ((t * c.factor) - g.min_h) / g.l_px_x - (1.f / 2.f);   // :45-50
-        c.u = -(g.d_so / den);                                        // :139
-        return c;
-    }
-
     // x / c for a divisor c that is constant over the launch, with r = RN(1 / c): one multiply and two FMAs
     // (Markstein's correction step) instead of the ~10-instruction IEEE sequence. Only used after
     // fastdiv_validate_kernel has checked, for THIS c and EVERY fp32 x, that the result has the bits of x / c.
@@ -78,6 +64,26 @@ namespace
         const float q = x * r;
         const float e = __builtin_fmaf(-q, c, x); // exact remainder
         return __builtin_fmaf(e, r, q);
+    }
+
+    // src/openmp/backprojection.cpp:116-129,139 for one (x,y) column; K, L are global voxel indices. FD: the division
+    // by the horizontal pixel pitch uses the validated multiply + 2 FMA form (h = q - 0.5 has the shape the exhaustive
+    // check covers; an h beyond +-2^24 makes the column invalid either way).
+    template <bool FD>
+    __device__ __forceinline__ ColConst column_constants(const BpParams& g, uint32_t K, uint32_t L)
+    {
+        const float x_k = g.x_base + static_cast<float>(K) * g.l_vx_x; // :39-43
+        const float y_l = g.y_base + static_cast<float>(L) * g.l_vx_y;
+        const float s = x_k * g.cos_phi + y_l * g.sin_phi;  // :121
+        const float t = -x_k * g.sin_phi + y_l * g.cos_phi; // :122
+        const float den = s + g.d_so;
+        ColConst c;
+        c.factor = g.d_sd / den; // :125
+        const float b = (t * c.factor) - g.min_h;
+        const float q = FD ? div_by_constant(b, g.l_px_x, g.rcp_l_px_x) : b / g.l_px_x;
+        c.h = q - (1.f / 2.f);     // :45-50
+        c.u = -(g.d_so / den);     // :139
+        return c;
     }
 
     // v detector coordinate of slice z_m for a column with magnification `factor` (:130-133, :45-50)
@@ -247,7 +253,7 @@ namespace
                                             uint32_t m0, uint32_t m1, uint32_t lane, uint32_t box_floats)
     {
         const uint32_t ci = lane & 3u;
-        const ColConst c = column_constants(g, g.k_off + ((ci & 1u) ? k1 : k0), g.l_off + ((ci & 2u) ? l1 : l0));
+        const ColConst c = column_constants<false>(g, g.k_off + ((ci & 1u) ? k1 : k0), g.l_off + ((ci & 2u) ? l1 : l0));
         float hmin = c.h, hmax = c.h, fmin = c.factor, fmax = c.factor;
 #pragma unroll
         for(int m = 1; m <= 2; m <<= 1)
@@ -390,7 +396,7 @@ namespace
     __device__ __forceinline__ Column make_column(const BpParams& g, const Box& b, uint32_t K, uint32_t L, float z_first,
                                                   float z_last)
     {
-        const ColConst c = column_constants(g, K, L);
+        const ColConst c = column_constants<FD>(g, K, L);
         const float x1 = floorf(c.h); // :55-58
         const float x2 = x1 + 1.f;
         const bool x_valid = (x1 >= 0.f) && (x2 < g.p_dim_x_f); // :65-66
@@ -701,6 +707,8 @@ namespace
         float cos_phi[FUSED_MAX];
     };
 
+    // (Double-buffering the box with the next projection's loads kept in flight was measured slower: the kernel is
+    // bound by vector ALU issue, not by staging latency, and the extra live registers cost occupancy.)
     template <int TZ, bool NT, bool FD>
     __global__ void __launch_bounds__(256) bp_fused_kernel(const FusedParams fp)
     {
@@ -796,7 +804,7 @@ namespace
         const uint32_t m = blockIdx.z;
         if(k >= g.v_dim_x)
             return;
-        const ColConst c = column_constants(g, g.k_off + k, g.l_off + l);
+        const ColConst c = column_constants<false>(g, g.k_off + k, g.l_off + l);
         const float z_m = g.z_base + static_cast<float>(g.m_off + m) * g.l_vx_z;
         const float x = c.h;
         const float y = v_coordinate<false>(g, z_m, c.factor);
@@ -882,16 +890,9 @@ namespace
         g.ntz = (g.v_dim_z + NW - 1u) / NW;
         uint32_t blocks = grid_blocks(g);
         const uint32_t lds_bytes = g.lds_floats * sizeof(float);
-        if(lds_bytes > 64u * 1024u)
-        {
-            static thread_local bool raised = false; // per host thread == per device (one ctx per thread)
-            if(!raised)
-            {
-                PARIS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bp_slice_kernel<NW, RPL, NT, FD>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                raised = true;
-            }
-        }
+        if(lds_bytes > 64u * 1024u) // beyond the default dynamic-LDS limit (only with a raised box budget): per launch, cheap
+            PARIS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bp_slice_kernel<NW, RPL, NT, FD>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL((bp_slice_kernel<NW, RPL, NT, FD>), dim3(blocks), dim3(NW * 64), lds_bytes, stream, g);
         return PARIS_HIP_SUCCESS;
     }
@@ -1027,10 +1028,17 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     g.min_h = detector_min(p_dim_x, g.l_px_x, delta_s);
     g.min_v = detector_min(p_dim_y, g.l_px_y, delta_t);
     g.rcp_l_px_y = 1.f / g.l_px_y;
+    g.rcp_l_px_x = 1.f / g.l_px_x;
     fd = false;
     if(ctx->bp_fastdiv != 0)
+    {
+        bool fd_x = false; // both pitches must pass (usually the same divisor: one cached check)
         if(int rc = fastdiv_is_exact(ctx, g.l_px_y, &fd))
             return rc;
+        if(int rc = fastdiv_is_exact(ctx, g.l_px_x, &fd_x))
+            return rc;
+        fd = fd && fd_x;
+    }
     g.p_dim_x_f = static_cast<float>(p_dim_x);
     g.p_dim_y_f = static_cast<float>(p_dim_y);
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
