@@ -437,7 +437,8 @@ namespace
         const int rrel = y1i - b.by0;
         const int bhs_m2 = b.bhs - 2;
         const int rc = min(max(rrel, 0), max(bhs_m2, 0));
-        const int base = rc * b.stride + max(col.xoff, 0);
+        // rc < 2^12 and stride < 2^14: the 24-bit multiply-add is one full-rate instruction (v_mul_lo_u32 is quarter rate)
+        const int base = __mul24(rc, b.stride) + max(col.xoff, 0);
         float q11 = lds_box[base];
         float q21 = lds_box[base + 1];
         float q12 = lds_box[base + b.stride];
@@ -766,12 +767,13 @@ namespace
                     col[j] = make_column<FD>(g, box, g.k_off + k + j, g.l_off + l, z_first, z_last);
                     all_fast = all_fast && col[j].fast;
                 }
-                auto add_projection = [&](auto fast_tag) {
+                auto add_projection = [&](auto fast_tag, auto full_tag) {
                     constexpr bool FAST = decltype(fast_tag)::value;
+                    constexpr bool FULL = decltype(full_tag)::value; // whole tile: no per-slice test, one straight block
 #pragma unroll
                     for(int z = 0; z < TZ; ++z)
                     {
-                        if(static_cast<uint32_t>(z) < mcount) // uniform; no break, so the loop unrolls and acc stays in registers
+                        if(FULL || static_cast<uint32_t>(z) < mcount) // uniform; no break, so acc stays in registers
                         {
                             const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + z) * g.l_vx_z; // :118
                             acc[z].x += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[0]);
@@ -781,10 +783,12 @@ namespace
                         }
                     }
                 };
-                if(all_fast)
-                    add_projection(std::true_type{});
+                if(all_fast && mcount == TZ)
+                    add_projection(std::true_type{}, std::true_type{});
+                else if(all_fast)
+                    add_projection(std::true_type{}, std::false_type{});
                 else
-                    add_projection(std::false_type{});
+                    add_projection(std::false_type{}, std::false_type{});
             }
         }
 #pragma unroll
@@ -1204,7 +1208,7 @@ extern "C" int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p,
     }
 
     const bool nt = ctx->bp_nt != 0;
-    const bool tz16 = ctx->bp_tz == 16u;
+    const bool tz16 = ctx->bp_tz != 8u; // 16 slices per tile unless 8 is asked for (tools/tune_bp.py --fused)
     for(uint32_t first = 0; first < n_proj; first += FUSED_MAX)
     {
         const uint32_t n = std::min<uint32_t>(FUSED_MAX, n_proj - first);

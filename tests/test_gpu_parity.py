@@ -472,7 +472,7 @@ def test_make_subvolume_information(be):
     assert info.geo.dim_z * 8192 * 8192 * 4 < 288e9
 
 
-@pytest.mark.parametrize("n_proj,tz,lds_bytes", [(9, 0, 0), (40, 0, 0), (9, 16, 0), (5, 0, 1024), (33, 16, 4096)])
+@pytest.mark.parametrize("n_proj,tz,lds_bytes", [(9, 0, 0), (40, 0, 0), (9, 8, 0), (5, 0, 1024), (33, 8, 4096)])
 def test_backproject_fused_batch_bit_exact(be, oracle, n_proj, tz, lds_bytes):
     """paris_hip_backproject_batch's fused kernel (n_proj projections per launch, split at 32) adds the projections
     to every voxel in projection order: bit-identical to the oracle's sequential loop. Partial tiles in x, y, z;
