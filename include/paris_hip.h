@@ -127,8 +127,8 @@ int paris_hip_memcpy_volume_d2h(paris_hip_ctx* ctx, float* h_dst, const float* d
 int paris_hip_memset_volume(paris_hip_ctx* ctx, float* d_ptr, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z);
 
 /* ---- make_subvolume_information (src/cuda/subvolume_information.cpp:63-118) ---------------------- */
-/* Splits dim_z into `num` slabs (+ remainder on the last) so that one slab plus `proj_slots` projections
- * fits in the free memory of each of `n_devices` devices. n_devices <= 0 means all visible devices. */
+/* Splits dim_z into `num` slabs (+ remainder on the last) so that (volume + 10 projections) / devices fits in the free
+ * memory of each of `n_devices` devices, doubling the slab count until it does. n_devices <= 0: all visible devices. */
 int paris_hip_make_subvolume_information(const paris_volume_geometry* vol_geo,
                                          const paris_detector_geometry* det_geo, int n_devices,
                                          paris_subvolume_info* out);

@@ -613,6 +613,47 @@ def test_large_slab_properties(be, oracle):
     assert_bit_equal(run(2.0, z0, nz), full * np.float32(2.0))
 
 
+def test_config3_4_geometry_slab_crops(be, oracle):
+    """BASELINE configs 3 / 4 geometry (2048^2 detector, 2048^3 grid): part of slab 7 of 8 (v_offset 1792, 24 slices =
+    one and a half tiles deep) through the default kernel path (y-band tile order, 4-pixel staging, fast division),
+    then the same through the fused batch entry; oracle crops at a corner, an edge and the middle."""
+    n = 2048
+    g = (n, n, 0.2, 0.2, 0, 0, 500, 500, 360.0 / 1440)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
+    ovg = oracle.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
+    v_offset, nz = 1792, 24
+    idxs = (3, 500, 1111)
+    projs = [oracle.lcg_projection(n, n, i) - np.float32(0.5) for i in idxs]
+    crops = {}
+    for (x1, y1, z1) in ((0, 0, 0), (1984, 700, 8), (1000, 1984, 16)):
+        roi = oracle.RegionOfInterest(x1, x1 + 64, y1, y1 + 64, 0, n)
+        want = np.zeros((8, 64, 64), np.float32)
+        for i, p in zip(idxs, projs):
+            s, c, ds, dt = oracle.backproject_constants(odet, i)
+            oracle.backproject(want, p, v_offset + z1, odet, ovg, s, c, ds, dt, roi)
+        crops[(x1, y1, z1)] = want
+
+    stack = be.make_projection_device(n, n * len(idxs))
+    be.copy_h2d(B.Projection(np.ascontiguousarray(np.concatenate(projs)), n, n * len(idxs)), stack)
+    sc = [B.stage_angle(det, i) for i in idxs]
+    for fused in (False, True):
+        d_v = be.make_volume_device(n, n, nz)
+        if fused:
+            be.backproject_batch(stack.ptr, stack.pitch, stack.pitch * n, len(idxs), n, n, d_v, v_offset, det, vg, False, None,
+                                 [s for s, _ in sc], [c for _, c in sc], 0.0, 0.0)
+        else:
+            for j, i in enumerate(idxs):
+                p = be.wrap_projection(stack.ptr + j * stack.pitch * n, stack.pitch, n, n, idx=i)
+                B.backproject(be, p, d_v, v_offset, det, vg, False, False, None)
+        got = volume_to_host(be, d_v)
+        be.free(d_v)
+        for (x1, y1, z1), want in crops.items():
+            assert_bit_equal(got[z1:z1 + 8, y1:y1 + 64, x1:x1 + 64], want)
+    be.free(stack)
+
+
 def test_torch_memory_interop(be, oracle, kat_golden):
     """PyTorch as plumbing: volume and projections owned by torch tensors, kernels enqueued on torch's stream."""
     torch = pytest.importorskip("torch")
