@@ -14,6 +14,8 @@ Workloads (BASELINE.json configs; geometry per SURVEY.md 8d: l_px 0.2 mm, d_so =
                 total work is fixed, so "scaling" is "strong". No collective on the data path.
   c2            1024^3 volume, 720 projections @ 1024x1024.
   c1            256^3 volume, 360 projections @ 512x512.
+  c5            4096^3 grid with the {1024..3072}^3 ROI (2048^3 voxels allocated), 3600 projections, stored as IEEE half
+                after filtering; the ROI is split into N z-slabs like c3.
 
 The JSON line also carries
   roofline      for the dominant kernel (backprojection): algorithmic bytes per launch (8 B per voxel-update +
@@ -41,6 +43,10 @@ WORKLOADS = {
                name="1024^3 volume, 720 projections @ 1024x1024 fp32"),
     "c1": dict(n_row=512, n_col=512, n_proj=360, vol=(256, 256, 256),
                name="256^3 volume, 360 projections @ 512x512 fp32"),
+    # BASELINE config 5: the allocated output is the 2048^3 ROI of the 4096^3 grid; projections are rounded to IEEE
+    # half after filtering and backprojected with fp32 interpolation and accumulation
+    "c5": dict(n_row=2048, n_col=2048, n_proj=3600, vol=(4096, 4096, 4096), roi=(1024, 3072, 1024, 3072, 1024, 3072),
+               f16=True, name="4096^3 grid, 2048^3 ROI, 3600 projections @ 2048x2048 fp16-in/fp32-accum"),
 }
 
 
@@ -165,7 +171,9 @@ def main():
         w["vol"] = (w["vol"][0], w["vol"][1], min(args.slices, w["vol"][2]))
         w["name"] += " [rehearsal: %d slices]" % w["vol"][2]
     det, vol_geo = geometry(B, w)
-    info = sharding.make_subvolume_info(vol_geo, world)  # one z-slab per rank
+    roi = B.RegionOfInterest(*w["roi"]) if "roi" in w else None
+    out_geo = B.apply_roi(vol_geo, *w["roi"]) if roi is not None else vol_geo  # what is allocated: the ROI (src/main.cpp:124-130)
+    info = sharding.make_subvolume_info(out_geo, world)  # one z-slab per rank
     z_first, z_count = sharding.slab_of_task(info, rank)
 
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -177,8 +185,10 @@ def main():
     gen.manual_seed(12345 + rank)
     raw = torch.rand((args.batch, n_col, n_row), generator=gen, device=dev, dtype=torch.float32)
     work = torch.empty_like(raw)
-    vol = torch.zeros((z_count, vol_geo.dim_y, vol_geo.dim_x), device=dev, dtype=torch.float32)
-    d_vol = be.wrap_volume(vol.data_ptr(), vol_geo.dim_x, vol_geo.dim_y, z_count, owner=vol)
+    vol = torch.zeros((z_count, out_geo.dim_y, out_geo.dim_x), device=dev, dtype=torch.float32)
+    d_vol = be.wrap_volume(vol.data_ptr(), out_geo.dim_x, out_geo.dim_y, z_count, owner=vol)
+    f16 = bool(w.get("f16"))
+    half = torch.empty((n_col, n_row), device=dev, dtype=torch.float16) if f16 else None
     pitch = work.stride(1) * 4
     projs = [be.wrap_projection(work[b].data_ptr(), pitch, n_row, n_col, owner=work) for b in range(args.batch)]
 
@@ -189,7 +199,13 @@ def main():
             work[b].copy_(raw[b], non_blocking=True)                          # stands in for the upload
             B.weight(be, p, det)                                              # src/main.cpp:102
             B.filter(be, p, det)                                              # :103
-            B.backproject(be, p, d_vol, z_first, det, vol_geo, False, False, None)  # :104
+            if f16:
+                sn, cs = B.stage_angle(det, p.idx)
+                B._lib.check(be._L.paris_hip_convert_projection_f16(be._ctx, p.ptr, p.pitch, half.data_ptr(), n_row * 2, n_row,
+                                                                   n_col), "paris_hip_convert_projection_f16")
+                be.backproject_f16(half.data_ptr(), n_row * 2, n_row, n_col, d_vol, z_first, det, vol_geo, True, roi, sn, cs, 0.0, 0.0)
+            else:
+                B.backproject(be, p, d_vol, z_first, det, vol_geo, False, roi is not None, roi)  # :104
 
     def barrier():
         if dist is not None:
@@ -221,7 +237,7 @@ def main():
 
     # ---- extension, outside the headline: the same step with ONE fused launch per batch (paris_hip_backproject_batch)
     fused = None
-    if args.fused_steps > 0:
+    if args.fused_steps > 0 and not f16 and roi is None:
         sc = [B.stage_angle(det, b) for b in range(w["n_proj"])]
         stride = work.stride(0) * 4
 
@@ -251,14 +267,14 @@ def main():
             tf = float(t.item())
         fms = be.backproject_timing_collect()
         fused = {"steps": args.fused_steps, "seconds": tf, "kernel_ms": sum(fms) / max(1, len(fms))}
-    voxels_rank = float(z_count) * vol_geo.dim_x * vol_geo.dim_y
-    voxels_all = float(vol_geo.dim_z) * vol_geo.dim_x * vol_geo.dim_y
+    voxels_rank = float(z_count) * out_geo.dim_x * out_geo.dim_y
+    voxels_all = float(out_geo.dim_z) * out_geo.dim_x * out_geo.dim_y
     updates_all = voxels_all * args.batch * args.steps
 
     if rank == 0:
         traffic, traffic_src = measured_traffic(w, world)
         avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
-        algo_bytes = 8.0 * voxels_rank + 4.0 * n_row * n_col  # per launch: RMW of the slab + one projection pass
+        algo_bytes = 8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col  # per launch: RMW of the slab + one projection pass
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "GVoxel-updates/s (voxels x projections / s), FDK hot path weight+filter+backproject",
@@ -271,12 +287,12 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f16-in/f32" if f16 else "f32",
             "data": "synthetic (uniform noise projections generated on device; zero-initialised volume)",
             "config": {
                 "workload": w["name"] + (", 1 GPU" if world == 1 else ", %d z-slabs on %d GPUs" % (world, world)),
                 "projections_per_step": args.batch,
-                "slab_per_gpu": [vol_geo.dim_x, vol_geo.dim_y, z_count],
+                "slab_per_gpu": [out_geo.dim_x, out_geo.dim_y, z_count],
                 "parallelism": "z-slab per GPU, no collective on the data path",
                 "backproject_kernel_ms": avg_ms,
                 "backproject_GVox_per_s_per_gpu": voxels_rank / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,

@@ -1047,9 +1047,9 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     g.p_dim_y_f = static_cast<float>(p_dim_y);
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
     g.tz = tz;
-    // default mapping: a band of y tiles per XCD when the bands are thick enough to keep every XCD busy (volumes of
-    // >= 1024 rows), else a contiguous run of tiles per XCD
-    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : ((v_dim_y + 15u) / 16u >= 64u ? 8u : 5u);
+    // default mapping: a contiguous run of tiles per XCD (best or within 0.4 % of the best on 1024^3 ... 2048^3 and slabs;
+    // the y-band mapping 8 ties at 2048 rows and loses 12 % at 1024: tools/ab_bp.py, tools/tune_bp.py)
+    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : 5u;
     g.store_sc1 = ctx->bp_nt == 2 ? 1u : 0u;
     // 4-pixel staging needs every detector row to start 16-byte (half: 8-byte) aligned
     g.stage_vec4 = (ctx->bp_stage_vec4 != 0 && g.p_pitch % 4u == 0 && reinterpret_cast<uintptr_t>(d_p) % (4u * px) == 0)
