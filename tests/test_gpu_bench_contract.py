@@ -1,0 +1,52 @@
+"""bench.py's output contract on a small workload (N = 1), and a rehearsal of its N = 2 path with both ranks sharing
+the one GPU of the test box over gloo (the real multi-GPU run uses RCCL, one rank per GPU)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def last_json_line(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, text  # exactly one JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c1", "--steps", "3", "--warmup", "1",
+                        "--cpu-budget", "2", "--fused-steps", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    d = last_json_line(r.stdout)
+    for k in REQUIRED + ["cpu_baseline", "fused_extension"]:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "GVoxel-updates/s" and d["value"] > 0 and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches_timed"] == 3 * 8
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_two_rank_rehearsal():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload",
+                        "c1", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--device", "0", "--fused-steps", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["slab_per_gpu"] == [256, 256, 128]  # 256 slices split over two ranks
+    assert "cpu_baseline" not in d                          # rank 0 at N = 1 only
