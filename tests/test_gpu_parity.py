@@ -654,6 +654,60 @@ def test_config3_4_geometry_slab_crops(be, oracle):
     be.free(stack)
 
 
+def test_empty_and_degenerate_arguments(be, oracle, kat_golden):
+    """Empty volumes are a no-op, empty or inconsistent projections are rejected, nothing is touched."""
+    import ctypes as C
+    L = _lib.load()
+    det = B.DetectorGeometry(*KAT)
+    vg = B.calculate_volume_geometry(det)
+    d_p = to_device(be, kat_golden["filtered"][0])
+    d_v = be.make_volume_device(8, 8, 8)
+    args = lambda pdx, pdy, vdx, vdy, vdz, pitch: L.paris_hip_backproject(  # noqa: E731
+        be._ctx, d_p.ptr, pitch, pdx, pdy, d_v.ptr, vdx, vdy, vdz, 0, C.byref(det), C.byref(vg), 0, None, 0.0, 1.0, 0.0, 0.0)
+    assert args(64, 48, 0, 8, 8, d_p.pitch) == _lib.SUCCESS      # empty volume: nothing to do
+    assert args(64, 48, 8, 8, 0, d_p.pitch) == _lib.SUCCESS
+    assert args(0, 48, 8, 8, 8, d_p.pitch) == _lib.ERROR_INVALID_ARGUMENT   # empty projection
+    assert args(64, 48, 8, 8, 8, 100) == _lib.ERROR_INVALID_ARGUMENT        # pitch shorter than a row
+    assert args(64, 48, 8, 8, 8, 258) == _lib.ERROR_INVALID_ARGUMENT        # pitch not a multiple of the pixel size
+    assert L.paris_hip_backproject(be._ctx, d_p.ptr, d_p.pitch, 64, 48, d_v.ptr, 8, 8, 8, 0, C.byref(det), C.byref(vg), 1, None,
+                                   0.0, 1.0, 0.0, 0.0) == _lib.ERROR_INVALID_ARGUMENT  # ROI enabled without a ROI
+    assert np.count_nonzero(volume_to_host(be, d_v)) == 0
+    assert L.paris_hip_weight(be._ctx, d_p.ptr, d_p.pitch, 0, 48, 0, 0, 1, 1, 1) == _lib.SUCCESS
+    assert L.paris_hip_backproject_batch(be._ctx, d_p.ptr, d_p.pitch, d_p.pitch * 48, 0, 64, 48, d_v.ptr, 8, 8, 8, 0, C.byref(det),
+                                         C.byref(vg), 0, None, (C.c_float * 1)(), (C.c_float * 1)(), 0.0, 0.0) == _lib.SUCCESS
+    be.free(d_p)
+    be.free(d_v)
+
+
+def test_beyond_2_to_32_voxels(be, oracle):
+    """64-bit voxel indexing (the reference's 32-bit arithmetic breaks here): a 2048 x 2048 x 1040 slab holds
+    2^32 + 67 M voxels; its last 16 slices (entirely beyond element 2^32) must equal a small slab run with the matching
+    offset, and an oracle crop."""
+    n = 2048
+    g = (n, n, 0.2, 0.2, 0, 0, 500, 500, 0.25)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
+    ovg = oracle.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
+    nz, z0 = 1040, 500
+    p = oracle.lcg_projection(n, n, 9) - np.float32(0.5)
+    d_p = to_device(be, p, idx=77)
+    big = be.make_volume_device(n, n, nz)
+    small = be.make_volume_device(n, n, 16)
+    B.backproject(be, d_p, big, z0, det, vg, False, False, None)
+    B.backproject(be, d_p, small, z0 + nz - 16, det, vg, False, False, None)
+    tail = be.wrap_volume(big.ptr + (nz - 16) * n * n * 4, n, n, 16)  # byte offset 4 * (2^32 + ...): past 16 GiB
+    a, b = volume_to_host(be, tail), volume_to_host(be, small)
+    assert_bit_equal(a, b)
+    roi = oracle.RegionOfInterest(900, 964, 1000, 1064, 0, n)
+    want = np.zeros((4, 64, 64), np.float32)
+    s, c, ds, dt = oracle.backproject_constants(odet, 77)
+    oracle.backproject(want, p, z0 + nz - 16 + 5, odet, ovg, s, c, ds, dt, roi)
+    assert_bit_equal(a[5:9, 1000:1064, 900:964], want)
+    for v in (big, small, d_p):
+        be.free(v)
+
+
 def test_torch_memory_interop(be, oracle, kat_golden):
     """PyTorch as plumbing: volume and projections owned by torch tensors, kernels enqueued on torch's stream."""
     torch = pytest.importorskip("torch")

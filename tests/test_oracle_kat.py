@@ -171,3 +171,23 @@ def test_bit_exact_checksums_with_the_surveys_fft(oracle, kat):
 
     assert survey_fnv(recon((61, 67, 67), 0), kat) == kat["full"]["fnv_mkl"]
     assert survey_fnv(recon((31, 67, 67), 30), kat) == kat["slab"]["fnv_mkl"]
+
+
+def test_committed_golden_fixtures_are_the_oracles_output(oracle, golden_dir):
+    """tests/golden/*.npz must be exactly what tests/golden/make_golden.py produces from the pinned oracle."""
+    gold = np.load(os.path.join(golden_dir, "kat.npz"))
+    det = oracle.DetectorGeometry(64, 48, 0.2, 0.25, 1.5, -0.75, 100, 200, 45)
+    vg = oracle.calculate_volume_geometry(det)
+    p0 = oracle.lcg_projection(64, 48, 0)
+    oracle.weight(p0, det)
+    assert np.array_equal(p0, gold["weighted_p0"])
+    filtered = []
+    vol = oracle.reconstruct(det, vg, 8, filtered_out=filtered)
+    assert np.array_equal(np.stack(filtered), gold["filtered"])
+    assert np.array_equal(vol, gold["volume"])
+    for n in (128, 1024, 2048, 4096):
+        assert np.array_equal(oracle.make_filter(n, 0.2), gold["k_%d" % n])
+    cube = np.load(os.path.join(golden_dir, "cube64.npz"))
+    d = oracle.DetectorGeometry(64, 64, 0.2, 0.2, 0, 0, 100, 200, 45.0)
+    v = oracle.reconstruct(d, oracle.calculate_volume_geometry(d), 8)
+    assert np.array_equal(v[31:34], cube["slices"]) and v.sum(dtype=np.float64) == float(cube["sum"])
