@@ -14,13 +14,26 @@
 #ifndef PARIS_AMD_HOST_HIP_BACKEND_H_
 #define PARIS_AMD_HOST_HIP_BACKEND_H_
 
+#include <cstddef>
 #include <cstdint>
 #include <map>
 #include <memory>
 #include <string>
 #include <vector>
 
+#if defined(PARIS_HIP_INSIDE_PARIS)
+// Installed as src/hip/backend.h of a PARIS checkout: PARIS's own value types are used and handed to the C ABI by
+// pointer (they are field-for-field the C structs: checked below).
+#include "../exception.h"
+#include "../geometry.h"
+#include "../projection.h"
+#include "../region_of_interest.h"
+#include "../subvolume_information.h"
+#include "../volume.h"
+#include "paris_hip.h"
+#else
 #include "../types.h"
+#endif
 
 namespace paris
 {
@@ -30,6 +43,19 @@ namespace paris
 
         namespace detail
         {
+            // PARIS value types -> C ABI structs. With ../types.h they are the same types; inside PARIS they are
+            // layout-identical PODs.
+            template <typename To, typename From>
+            inline auto as_c(const From& v) noexcept -> const To*
+            {
+                static_assert(sizeof(To) == sizeof(From) && alignof(To) == alignof(From), "PARIS type and C ABI struct differ");
+                return reinterpret_cast<const To*>(&v);
+            }
+            static_assert(offsetof(detector_geometry, delta_phi) == offsetof(paris_detector_geometry, delta_phi), "detector_geometry");
+            static_assert(offsetof(volume_geometry, l_vx_z) == offsetof(paris_volume_geometry, l_vx_z), "volume_geometry");
+            static_assert(offsetof(region_of_interest, z2) == offsetof(paris_region_of_interest, z2), "region_of_interest");
+            static_assert(offsetof(subvolume_info, num) == offsetof(paris_subvolume_info, num), "subvolume_info");
+
             struct ctx_deleter { void operator()(paris_hip_ctx* c) const noexcept { paris_hip_ctx_destroy(c); } };
 
             struct thread_state
@@ -197,9 +223,16 @@ namespace paris
         // ---- subvolume planning (src/cuda/subvolume_information.cpp:63-118) ---------------------------------------
         inline auto make_subvolume_information(const volume_geometry& vol_geo, const detector_geometry& det_geo) -> subvolume_info
         {
-            subvolume_info info{};
-            detail::construction_check(paris_hip_make_subvolume_information(&vol_geo, &det_geo, 0, &info),
+            paris_subvolume_info c_info{};
+            detail::construction_check(paris_hip_make_subvolume_information(detail::as_c<paris_volume_geometry>(vol_geo),
+                                                                            detail::as_c<paris_detector_geometry>(det_geo), 0, &c_info),
                                        "make_subvolume_information()");
+            subvolume_info info{};
+            info.geo.dim_x = c_info.geo.dim_x;
+            info.geo.dim_y = c_info.geo.dim_y;
+            info.geo.dim_z = c_info.geo.dim_z;
+            info.geo.remainder = c_info.geo.remainder;
+            info.num = c_info.num;
             return info;
         }
 
@@ -229,8 +262,10 @@ namespace paris
                                 const region_of_interest& roi, float sin, float cos, float delta_s, float delta_t) -> void
         {
             detail::runtime_check(paris_hip_backproject(current_ctx(), p.buf.get(), p.buf.pitch(), p.dim_x, p.dim_y, v.buf.get(),
-                                                        v.dim_x, v.dim_y, v.dim_z, v_offset, &det_geo, &vol_geo, enable_roi ? 1 : 0,
-                                                        &roi, sin, cos, delta_s, delta_t), "backproject()");
+                                                        v.dim_x, v.dim_y, v.dim_z, v_offset, detail::as_c<paris_detector_geometry>(det_geo),
+                                                        detail::as_c<paris_volume_geometry>(vol_geo), enable_roi ? 1 : 0,
+                                                        detail::as_c<paris_region_of_interest>(roi), sin, cos, delta_s, delta_t),
+                                  "backproject()");
         }
     }
 }

@@ -118,3 +118,40 @@ def test_product_does_not_import_the_oracle():
                 if b"\0" in raw:
                     continue  # a built binary (e.g. the paris.hip executable), not source
                 assert b"oracle" not in raw.lower(), os.path.join(dirpath, f)
+
+
+REFERENCE = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference tree exists only in the build container")
+def test_reference_wrappers_compile_against_the_hip_backend(tmp_path):
+    """Drop-in check at the source level: the reference's own stage wrappers (the ones that need neither Boost nor
+    FFTW) are compiled, unmodified and where they lie, against namespace paris::hip installed as src/hip/backend.h with
+    the selector arm of INTEGRATION.md section 1. Syntax/semantic pass only (-fsyntax-only): nothing of the reference
+    is copied into this repo, built into the product or run."""
+    import subprocess
+    src = tmp_path / "src"
+    (src / "hip").mkdir(parents=True)
+    for name in ("geometry.h", "projection.h", "volume.h", "region_of_interest.h", "subvolume_information.h", "exception.h",
+                 "weighting.h", "weighting.cpp", "filtering.h", "filtering.cpp", "loader.h", "loader.cpp", "make_volume.h",
+                 "make_volume.cpp", "backprojection.h"):
+        os.symlink(os.path.join(REFERENCE, name), src / name)
+    os.symlink(os.path.join(ROOT, "paris_amd", "host", "paris", "hip", "backend.h"), src / "hip" / "backend.h")
+    # the selector a maintainer gets after adding the PARIS_ENABLE_HIP arm (INTEGRATION.md): only the chosen arm matters
+    (src / "backend.h").write_text('#ifndef PARIS_BACKEND_H_\n#define PARIS_BACKEND_H_\n#include "hip/backend.h"\n'
+                                   "namespace paris { namespace backend = hip; }\n#endif\n")
+    for unit in ("weighting.cpp", "filtering.cpp", "loader.cpp", "make_volume.cpp"):
+        r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-DPARIS_ENABLE_HIP", "-DPARIS_HIP_INSIDE_PARIS",
+                            "-I", os.path.join(ROOT, "include"), str(src / unit)], capture_output=True, text=True)
+        assert r.returncode == 0, unit + "\n" + r.stderr
+    # backprojection.h declares paris::backproject over backend types: its signature must be expressible too
+    probe = src / "probe.cpp"
+    probe.write_text('#include "backprojection.h"\n#include "hip/backend.h"\n'
+                     "void f(paris::backend::projection_device_type& p, paris::backend::volume_device_type& v,\n"
+                     "       const paris::detector_geometry& d, const paris::volume_geometry& g, const paris::region_of_interest& r)\n"
+                     "{ paris::backend::backproject(p, v, 0u, d, g, false, r, 0.f, 1.f, 0.f, 0.f); auto k = paris::backend::make_filter(8u, 1.f);\n"
+                     "  paris::backend::apply_filter(p, k, 8u, 1u); auto dev = paris::backend::get_devices(); paris::backend::set_device(dev[0]);\n"
+                     "  auto s = paris::backend::make_subvolume_information(g, d); (void)s; }\n")
+    r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-DPARIS_ENABLE_HIP", "-DPARIS_HIP_INSIDE_PARIS", "-I",
+                        os.path.join(ROOT, "include"), str(probe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
