@@ -654,6 +654,75 @@ def test_config3_4_geometry_slab_crops(be, oracle):
     be.free(stack)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PARIS_FUZZ_SEEDS", "24"))))
+def test_backproject_random_geometries_bit_exact(be, oracle, seed):
+    """Seeded random geometries: detector size and pitch, offsets of either sign, source / detector distances from a
+    narrow to a very wide cone, anisotropic voxels, a volume larger or smaller than the field of view, random ROI and
+    slab offset, random angles. Default kernel path (and the fused one for aligned volumes) vs the oracle, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    big = 4 if os.environ.get("PARIS_FUZZ_BIG") else 1
+    n_row = int(rng.integers(24, 200 * big))
+    n_col = int(rng.integers(16, 160 * big))
+    l_r, l_c = float(rng.choice([0.1, 0.2, 0.127, 0.4, 0.074])), float(rng.choice([0.1, 0.2, 0.25, 0.4]))
+    d_so = float(rng.uniform(40, 600))
+    d_od = float(rng.uniform(20, 600))
+    g = (n_row, n_col, l_r, l_c, float(rng.uniform(-6, 6)), float(rng.uniform(-6, 6)), d_so, d_od, float(rng.uniform(0.5, 40)))
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    hi = 400 if os.environ.get("PARIS_FUZZ_BIG") else 120
+    full = [int(rng.integers(20, hi)) for _ in range(3)]               # z, y, x of the full grid
+    if seed % 3 == 0:
+        full[2] = (full[2] + 3) // 4 * 4                               # 16-byte lanes + fused kernel
+    scale = [float(nat.l_vx_x * rng.uniform(0.4, 2.5)) for _ in range(3)]
+    # keep the grid inside the source orbit (the reference divides by s + d_so)
+    half_diag = 0.5 * np.hypot(full[2] * scale[0], full[1] * scale[1])
+    if half_diag > 0.8 * d_so:
+        f = 0.8 * d_so / half_diag
+        scale[0] *= f
+        scale[1] *= f
+    vg = B.VolumeGeometry(full[2], full[1], full[0], *scale)
+    ovg = oracle.VolumeGeometry(full[2], full[1], full[0], *scale)
+    use_roi = bool(seed % 2)
+    if use_roi:
+        x1, y1, z1 = (int(rng.integers(1, d // 3)) for d in (full[2], full[1], full[0]))
+        x2, y2, z2 = (int(rng.integers(2 * d // 3, d)) for d in (full[2], full[1], full[0]))
+        if seed % 3 == 0:
+            x2 = x1 + (x2 - x1) // 4 * 4
+        roi, oroi = B.RegionOfInterest(x1, x2, y1, y2, z1, z2), oracle.RegionOfInterest(x1, x2, y1, y2, z1, z2)
+        out = (z2 - z1, y2 - y1, x2 - x1)
+    else:
+        roi = oroi = None
+        out = tuple(full)
+    v_offset = int(rng.integers(0, max(1, out[0] // 2)))
+    dims = (out[0] - v_offset, out[1], out[2])
+    n_proj = 5
+    angles = [float(rng.uniform(0, 360)) for _ in range(n_proj)]
+    projs = [oracle.lcg_projection(n_row, n_col, 100 * seed + i) - np.float32(0.5) for i in range(n_proj)]
+    want = np.zeros(dims, np.float32)
+    for i, p in enumerate(projs):
+        s, c, ds, dt = oracle.backproject_constants(odet, i, True, angles[i])
+        oracle.backproject(want, p, v_offset, odet, ovg, s, c, ds, dt, oroi)
+
+    d_v = be.make_volume_device(dims[2], dims[1], dims[0])
+    for i, p in enumerate(projs):
+        d_p = to_device(be, p, idx=i, phi=angles[i])
+        B.backproject(be, d_p, d_v, v_offset, det, vg, True, use_roi, roi)
+        be.free(d_p)
+    assert_bit_equal(volume_to_host(be, d_v), want)
+    be.free(d_v)
+
+    if dims[2] % 4 == 0:  # the fused batch entry on the same case
+        stack = be.make_projection_device(n_row, n_col * n_proj)
+        be.copy_h2d(B.Projection(np.ascontiguousarray(np.concatenate(projs)), n_row, n_col * n_proj), stack)
+        sc = [B.stage_angle(det, i, True, angles[i]) for i in range(n_proj)]
+        d_v = be.make_volume_device(dims[2], dims[1], dims[0])
+        be.backproject_batch(stack.ptr, stack.pitch, stack.pitch * n_col, n_proj, n_row, n_col, d_v, v_offset, det, vg, use_roi,
+                             roi, [s for s, _ in sc], [c for _, c in sc], det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
+        assert_bit_equal(volume_to_host(be, d_v), want)
+        be.free(d_v)
+        be.free(stack)
+
+
 def test_empty_and_degenerate_arguments(be, oracle, kat_golden):
     """Empty volumes are a no-op, empty or inconsistent projections are rejected, nothing is touched."""
     import ctypes as C
