@@ -418,7 +418,8 @@ namespace
         const int r_lo = max(static_cast<int>(floorf(fminf(va, vb))), 0);                              // valid taps start at row 0
         const int r_hi = min(static_cast<int>(floorf(fmaxf(va, vb))), static_cast<int>(g.p_dim_y) - 2); // and end at dim_y - 2
         const bool rows_inside = (r_lo > r_hi) || (r_lo >= b.by0 && r_hi <= b.by0 + b.bhs - 2);
-        col.fast = !x_valid || (ordered && col.xoff >= 0 && rows_inside);
+        const bool finite_factor = (c.factor - c.factor) == 0.f; // with a finite factor v is never NaN (it may overflow to inf)
+        col.fast = !x_valid || (ordered && finite_factor && col.xoff >= 0 && rows_inside);
         return col;
     }
 
@@ -432,10 +433,22 @@ namespace
         const float v = v_coordinate<FD>(g, z_m, col.factor);
         const float y1 = floorf(v);
         const float y2 = y1 + 1.f;
-        const bool valid = (y1 >= 0.f) && (y2 < col.ymax); // :67-68 (+ x validity)
         const int y1i = static_cast<int>(y1);
         const int rrel = y1i - b.by0;
         const int bhs_m2 = b.bhs - 2;
+        bool valid;
+        if(FAST)
+        {
+            // For a `fast` column "valid" (:65-68) is the same as "row and row + 1 inside the staged box": valid taps are
+            // inside by construction of `fast`, and the box is clipped to the detector, so a row pair inside it is a
+            // valid pair (floor(v) as int equals the float exactly below 2^24; a non-finite v saturates the conversion
+            // far outside; `fast` excludes a non-finite factor, the only source of NaN). One unsigned compare, with the
+            // column's x validity folded into the limit.
+            const unsigned rowlim = col.ymax > 0.f ? static_cast<unsigned>(max(b.bhs - 1, 0)) : 0u;
+            valid = static_cast<unsigned>(rrel) < rowlim;
+        }
+        else
+            valid = (y1 >= 0.f) && (y2 < col.ymax); // :67-68 (+ x validity)
         const int rc = min(max(rrel, 0), max(bhs_m2, 0));
         // rc < 2^12 and stride < 2^14: the 24-bit multiply-add is one full-rate instruction (v_mul_lo_u32 is quarter rate)
         const int base = __mul24(rc, b.stride) + max(col.xoff, 0);
