@@ -118,6 +118,11 @@ int paris_hip_free_host(paris_hip_ctx* ctx, void* h_ptr);
 /* 2-D copies, pitches in bytes; projection rows are dim_x floats */
 int paris_hip_memcpy_projection_h2d(paris_hip_ctx* ctx, float* d_dst, size_t d_pitch, const float* h_src,
                                     size_t h_pitch, uint32_t dim_x, uint32_t dim_y);
+/* Extension: the same host -> device copy on a dedicated upload stream of the ctx, with the compute stream made to wait
+ * for it (hipStreamWaitEvent): the transfer overlaps kernels already queued. Use pinned host memory, and do not
+ * refill h_src or overwrite d_dst before the work that reads them has passed a fence; at most 16 uploads in flight. */
+int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, size_t d_pitch, const float* h_src, size_t h_pitch,
+                                uint32_t dim_x, uint32_t dim_y);
 int paris_hip_memcpy_projection_d2h(paris_hip_ctx* ctx, float* h_dst, size_t h_pitch, const float* d_src,
                                     size_t d_pitch, uint32_t dim_x, uint32_t dim_y);
 int paris_hip_memcpy_volume_h2d(paris_hip_ctx* ctx, float* d_dst, const float* h_src, uint32_t dim_x,

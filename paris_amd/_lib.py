@@ -71,6 +71,7 @@ SIGNATURES = {
     "paris_hip_malloc_host": (C.c_int, [_vp, _sz, _P(_vp)]),
     "paris_hip_free_host": (C.c_int, [_vp, _vp]),
     "paris_hip_memcpy_projection_h2d": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u32, _u32]),
+    "paris_hip_upload_projection": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u32, _u32]),
     "paris_hip_memcpy_projection_d2h": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u32, _u32]),
     "paris_hip_memcpy_volume_h2d": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32]),
     "paris_hip_memcpy_volume_d2h": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32]),

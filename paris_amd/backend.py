@@ -156,6 +156,14 @@ class Backend:
             d.off = h.off
         self.synchronize()
 
+    def upload(self, h, d):
+        """copy_h2d for a projection on the ctx's upload stream (paris_hip_upload_projection): returns without waiting;
+        kernels enqueued afterwards are ordered behind the transfer, kernels already queued overlap it."""
+        assert h.buf.dtype == np.float32 and h.dim_x == d.dim_x and h.dim_y == d.dim_y
+        check(self._L.paris_hip_upload_projection(self._ctx, d.ptr, d.pitch, h.ptr, h.buf.strides[0],
+                                                  h.dim_x, h.dim_y), "paris_hip_upload_projection")
+        d.idx, d.phi = h.idx, h.phi
+
     def copy_d2h(self, d, h):
         if isinstance(d, Projection):
             assert h.buf.dtype == np.float32 and h.dim_x == d.dim_x and h.dim_y == d.dim_y

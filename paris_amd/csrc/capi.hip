@@ -5,6 +5,7 @@
 // src/openmp/memory.cpp, src/openmp/subvolume_information.cpp). All implicit thread_local state of the
 // reference lives in paris_hip_ctx.
 #include "paris_hip_internal.h"
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstring>
@@ -132,6 +133,13 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
         (void)hipFree(ctx->d_sincos);
     if(ctx->stage_k != nullptr)
         (void)hipFree(ctx->stage_k);
+    if(ctx->upload_stream != nullptr)
+    {
+        (void)hipStreamSynchronize(ctx->upload_stream);
+        for(hipEvent_t e : ctx->upload_events)
+            (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(ctx->upload_stream);
+    }
     for(hipEvent_t e : ctx->bp_start)
         (void)hipEventDestroy(e);
     for(hipEvent_t e : ctx->bp_stop)
@@ -305,6 +313,34 @@ extern "C" int paris_hip_memcpy_projection_h2d(paris_hip_ctx* ctx, float* d_dst,
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
                                    hipMemcpyHostToDevice, ctx->stream));
+    return paris_hip_finish(ctx);
+}
+
+extern "C" int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, size_t d_pitch, const float* h_src, size_t h_pitch,
+                                           uint32_t dim_x, uint32_t dim_y)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(d_dst == nullptr || h_src == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    static const bool serial = [] { const char* e = std::getenv("PARIS_HIP_UPLOAD_STREAM"); return e != nullptr && e[0] == '0'; }();
+    if(serial) // diagnostic: PARIS_HIP_UPLOAD_STREAM=0 keeps the copy on the compute stream (A/B of the overlap)
+        return paris_hip_memcpy_projection_h2d(ctx, d_dst, d_pitch, h_src, h_pitch, dim_x, dim_y);
+    if(ctx->upload_stream == nullptr)
+    {
+        PARIS_HIP_TRY(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+        for(int i = 0; i < 16; ++i)
+        {
+            hipEvent_t e = nullptr;
+            PARIS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->upload_events.push_back(e);
+        }
+    }
+    hipEvent_t done = ctx->upload_events[ctx->uploads++ % ctx->upload_events.size()];
+    PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
+                                   hipMemcpyHostToDevice, ctx->upload_stream));
+    PARIS_HIP_TRY(hipEventRecord(done, ctx->upload_stream));
+    PARIS_HIP_TRY(hipStreamWaitEvent(ctx->stream, done, 0)); // kernels enqueued from now on see the uploaded frame
     return paris_hip_finish(ctx);
 }
 

@@ -51,6 +51,10 @@ struct paris_hip_ctx
     bool filter_r16_attr_set[5] = {false, false, false, false, false}; // LOG2N 10..14
     int filter_variant = 0; // 0: radix-16 register passes for N >= 1024, 1: radix-2 kernel for every N
     std::map<uint32_t, paris_hip_fft_plan> plans; // keyed by FFT length
+    // dedicated upload stream + ring of events ordering the compute stream behind each upload (paris_hip_upload_projection)
+    hipStream_t upload_stream = nullptr;
+    std::vector<hipEvent_t> upload_events;
+    uint64_t uploads = 0;
     // K cached by paris_hip_stage_filter (reference: thread_local static in src/filtering.cpp:42)
     float* stage_k = nullptr;
     uint32_t stage_k_size = 0;

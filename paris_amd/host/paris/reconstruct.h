@@ -5,8 +5,9 @@
 // sink shared by all threads.
 // What is rebuilt for the GPU:
 //   - the per-projection chain is enqueued asynchronously on the device's stream; the host thread meanwhile reads and
-//     converts the next HIS frame into one of `slots` pinned upload buffers, each guarded by a stream fence, so file
-//     I/O, upload and GPU work overlap instead of running strictly one after the other;
+//     converts the next HIS frame into one of `slots` pinned upload buffers (each slot = pinned host + device buffer,
+//     guarded by a stream fence recorded after its backprojection); the upload runs on a second stream and the
+//     compute stream waits for it by event, so file I/O, PCIe upload and GPU work all overlap;
 //   - geometry constants are derived per call and the slab offset is passed per task (Q1, Q2), the source restarts
 //     its frame index per task (Q5), slabs are written at their own slice offset (Q4);
 //   - slab planning is 64-bit and memory driven (paris_hip_make_subvolume_information) with an optional fixed count.
@@ -196,11 +197,11 @@ namespace paris
                     if(p.dim_x != n_row || p.dim_y != n_col)
                         throw stage_runtime_error{"projection size does not match the detector geometry"};
                     t0 = clock::now();
-                    rt(paris_hip_fence_wait(ctx, fence[slot]), "fence wait"); // the upload that last used this slot is done
+                    rt(paris_hip_fence_wait(ctx, fence[slot]), "fence wait"); // everything that last used this slot is done
                     std::memcpy(h_buf[slot], p.pixels.data(), frame_bytes);
-                    rt(paris_hip_memcpy_projection_h2d(ctx, d_buf[slot], d_pitch, h_buf[slot], static_cast<std::size_t>(n_row) * sizeof(float),
-                                                      n_row, n_col), "load()"); // :101
-                    rt(paris_hip_fence_record(ctx, fence[slot]), "fence record");
+                    // :101 -- on the upload stream, overlapping the kernels of the previous projections
+                    rt(paris_hip_upload_projection(ctx, d_buf[slot], d_pitch, h_buf[slot], static_cast<std::size_t>(n_row) * sizeof(float),
+                                                   n_row, n_col), "load()");
                     rt(paris_hip_stage_weight(ctx, d_buf[slot], d_pitch, n_row, n_col, &t.det_geo), "weight()"); // :102
                     rt(paris_hip_stage_filter(ctx, d_buf[slot], d_pitch, n_row, n_col, &t.det_geo), "filter()"); // :103
                     if(po.f16)
@@ -217,6 +218,7 @@ namespace paris
                         rt(paris_hip_stage_backproject(ctx, d_buf[slot], d_pitch, n_row, n_col, p.idx, p.phi, d_v, t.subvol_geo.dim_x,
                                                        t.subvol_geo.dim_y, dim_z, offset, &t.det_geo, &t.vol_geo, t.enable_angles,
                                                        t.enable_roi, &t.roi), "backproject()"); // :104
+                    rt(paris_hip_fence_record(ctx, fence[slot]), "fence record"); // slot reusable once its backprojection is done
                     rep.enqueue_s += since(t0);
                     slot = (slot + 1) % slots;
                     ++rep.projections;

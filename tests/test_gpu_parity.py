@@ -5,6 +5,7 @@ Bars (DESIGN.md "Numerics"):
   make_filter / apply_filter: the FFT is a third-party library in the reference (FFTW3f), so parity is to FFT
                               rounding: max-abs error <= 1e-5 * max|x| and relative L2 error <= 1e-5
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -505,6 +506,38 @@ def test_backproject_fused_batch_bit_exact(be, oracle, n_proj, tz, lds_bytes):
     assert_bit_equal(volume_to_host(be, d_v), want)
     be.free(d_v)
     be.free(stack)
+
+
+def test_upload_stream_orders_compute_behind_transfers(oracle, kat_golden):
+    """paris_hip_upload_projection on an asynchronous ctx: 8 frames go up on the upload stream while the
+    backprojections of the earlier ones are still queued; each backprojection must see its own frame. Two device
+    slots are reused, guarded by host-side fences the way the pipelined driver does it (reconstruct.h)."""
+    import torch
+    det = B.DetectorGeometry(*KAT)
+    vg = B.calculate_volume_geometry(det)
+    filtered = kat_golden["filtered"]
+    with B.Backend(0, synchronous=False) as abe:
+        L, ctx = abe._L, abe._ctx
+        pinned = [torch.from_numpy(np.ascontiguousarray(f)).pin_memory() for f in filtered]
+        slots = [abe.make_projection_device(64, 48) for _ in range(2)]
+        fences = []
+        for _ in slots:
+            f = C.c_void_p()
+            assert L.paris_hip_fence_create(ctx, C.byref(f)) == 0
+            fences.append(f)
+        d_v = abe.make_volume_device(67, 67, 61)
+        for i, t in enumerate(pinned):
+            s = i % len(slots)
+            assert L.paris_hip_fence_wait(ctx, fences[s]) == 0   # the backprojection that last read this slot is done
+            h = B.Projection(t.numpy(), 64, 48, idx=i)
+            abe.upload(h, slots[s])
+            B.backproject(abe, slots[s], d_v, 0, det, vg, False, False, None)
+            assert L.paris_hip_fence_record(ctx, fences[s]) == 0
+        abe.synchronize()
+        got = volume_to_host(abe, d_v)
+        for f in fences:
+            assert L.paris_hip_fence_destroy(ctx, f) == 0
+    assert_bit_equal(got, kat_golden["volume"])
 
 
 # ---- the whole hot path ------------------------------------------------------------------------------------------
