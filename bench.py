@@ -114,11 +114,15 @@ def cpu_baseline(w, budget_s):
         if n >= 2 and time.perf_counter() - t_start > budget_s:
             break
     updates = float(slices) * dx * dy * n
+    # whole hot path, scaled to the sample: weighting and filtering run once per projection for all dz slices of the
+    # real job, so the sample (slices of dz) is charged that share of them
+    share = float(slices) / dz
+    t_path = t_b + (t_w + t_f) * share
     return {
-        "value": updates / t_b / 1e9, "unit": "GVoxel-updates/s", "cores": cores, "kind": "port",
-        "sample": "%s geometry, %d central slices (z %d..%d) x %d projections; backproject %.2f s "
-                  "(weight %.2f s, filter %.2f s not in value)" % (w["name"], slices, z0, z0 + slices - 1, n,
-                                                                    t_b, t_w, t_f),
+        "value": updates / t_path / 1e9, "unit": "GVoxel-updates/s", "cores": cores, "kind": "port",
+        "sample": "%s geometry, %d central slices (z %d..%d) x %d projections: backproject %.2f s + %d/%d of "
+                  "weight %.2f s and filter %.2f s" % (w["name"], slices, z0, z0 + slices - 1, n, t_b, slices, dz,
+                                                       t_w, t_f),
     }
 
 
@@ -152,11 +156,13 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible -- the hot path has no CPU fallback")
-    dev_index = args.device if args.device >= 0 else local_rank
+    n_visible = torch.cuda.device_count()
+    # a launcher may give every rank its own single visible device (ROCR/HIP_VISIBLE_DEVICES): then LOCAL_RANK wraps
+    dev_index = args.device if args.device >= 0 else (local_rank if local_rank < n_visible else local_rank % n_visible)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # under torch.distributed.run, also at N = 1
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
