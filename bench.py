@@ -34,7 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+HBM_COPY_GBS = 6290.0  # same guide: measured copy rate (tools/membench*: 6.5 TB/s linear nontemporal read-modify-write here)
 
 WORKLOADS = {
     "c3": dict(n_row=2048, n_col=2048, n_proj=1440, vol=(2048, 2048, 2048),
@@ -143,6 +144,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of the N > 1 path "
                     "with several ranks sharing one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default: LOCAL_RANK)")
+    ap.add_argument("--row-band", type=int, default=1, help="1 (default): each rank uploads, weights and filters only the "
+                    "detector rows its z-slab can read (paris_hip_slab_row_band; the whole detector at N = 1); 0: all rows")
     ap.add_argument("--slices", type=int, default=0, help="rehearsal only: cap the volume depth (0 = the workload's)")
     args = ap.parse_args()
 
@@ -198,13 +201,19 @@ def main():
     pitch = work.stride(1) * 4
     projs = [be.wrap_projection(work[b].data_ptr(), pitch, n_row, n_col, owner=work) for b in range(args.batch)]
 
+    # f4: the detector rows this rank's slab can read for any angle; rows outside never reach its voxels
+    band_first, band_count = 0, n_col
+    if args.row_band:
+        band_first, band_count = B.slab_row_band(det, vol_geo, out_geo.dim_x, out_geo.dim_y, z_count, z_first, roi)
+    band = slice(band_first, band_first + band_count)
+
     def step(s):
         for b in range(args.batch):
             p = projs[b]
             p.idx = (s * args.batch + b) % w["n_proj"]
-            work[b].copy_(raw[b], non_blocking=True)                          # stands in for the upload
-            B.weight(be, p, det)                                              # src/main.cpp:102
-            B.filter(be, p, det)                                              # :103
+            work[b, band].copy_(raw[b, band], non_blocking=True)              # stands in for the upload
+            B.weight_rows(be, p, det, band_first, band_count)                 # src/main.cpp:102
+            B.filter_rows(be, p, det, band_first, band_count)                 # :103
             if f16:
                 sn, cs = B.stage_angle(det, p.idx)
                 B._lib.check(be._L.paris_hip_convert_projection_f16(be._ctx, p.ptr, p.pitch, half.data_ptr(), n_row * 2, n_row,
@@ -250,9 +259,9 @@ def main():
         def fused_step(s):
             idx = [(s * args.batch + b) % w["n_proj"] for b in range(args.batch)]
             for b in range(args.batch):
-                work[b].copy_(raw[b], non_blocking=True)
-                B.weight(be, projs[b], det)
-                B.filter(be, projs[b], det)
+                work[b, band].copy_(raw[b, band], non_blocking=True)
+                B.weight_rows(be, projs[b], det, band_first, band_count)
+                B.filter_rows(be, projs[b], det, band_first, band_count)
             be.backproject_batch(work.data_ptr(), pitch, stride, args.batch, n_row, n_col, d_vol, z_first, det, vol_geo, False,
                                  None, [sc[i][0] for i in idx], [sc[i][1] for i in idx], 0.0, 0.0)
 
@@ -299,13 +308,15 @@ def main():
                 "workload": w["name"] + (", 1 GPU" if world == 1 else ", %d z-slabs on %d GPUs" % (world, world)),
                 "projections_per_step": args.batch,
                 "slab_per_gpu": [out_geo.dim_x, out_geo.dim_y, z_count],
+                "detector_row_band_rank0": [band_first, band_count],
                 "parallelism": "z-slab per GPU, no collective on the data path",
                 "backproject_kernel_ms": avg_ms,
                 "backproject_GVox_per_s_per_gpu": voxels_rank / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel": "bp_tile_kernel (one projection per launch, 8 B per voxel-update)",
                 "launches_timed": len(kernel_ms),

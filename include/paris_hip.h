@@ -144,6 +144,12 @@ int paris_hip_make_subvolume_information(const paris_volume_geometry* vol_geo,
 int paris_hip_weight(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y, float h_min,
                      float v_min, float d_sd, float l_px_row, float l_px_col);
 
+/* Extension (f4): the same weighting restricted to rows [row_first, row_first + row_count) of the dim_y-row projection
+ * at d_p; row t keeps its own v_t, so the band is bit-identical to the same rows of a full paris_hip_weight. */
+int paris_hip_weight_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                          uint32_t row_first, uint32_t row_count, float h_min, float v_min, float d_sd,
+                          float l_px_row, float l_px_col);
+
 /* ---- filtering: backend::make_filter / apply_filter (src/openmp/filtering.cpp:139-219,
  *      src/cuda/filtering.cu:172-261) --------------------------------------------------------------- */
 /* K = tau * |rFFT_size(r)| with r the band-limited ramp of src/openmp/filtering.cpp:52-73. *d_k receives a
@@ -217,6 +223,22 @@ uint32_t paris_hip_filter_size(uint32_t n_row);
 /* paris::filter (src/filtering.cpp:32-45): builds K once per ctx, then paris_hip_apply_filter */
 int paris_hip_stage_filter(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
                            const paris_detector_geometry* det_geo);
+/* Extensions (f4): the two wrappers above on rows [row_first, row_first + row_count) of the projection at d_p only. With a
+ * band from paris_hip_slab_row_band (whole filter row pairs) the band's pixels are bit-identical to a full call. */
+int paris_hip_stage_weight_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                                uint32_t row_first, uint32_t row_count, const paris_detector_geometry* det_geo);
+int paris_hip_stage_filter_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                                uint32_t row_first, uint32_t row_count, const paris_detector_geometry* det_geo);
+/* Extension (f4; no reference counterpart): the detector rows [*row_first, *row_first +
+ * *row_count) that backprojecting into the slab (v_dim_*, v_offset, optional ROI; arguments as paris_hip_backproject)
+ * can read for ANY projection angle. Rows outside the band never contribute to the slab, so a driver may upload,
+ * weight (paris_hip_weight_rows) and filter (paris_hip_apply_filter on the band's rows) only the band and still get
+ * the bit-identical volume; the projection buffer keeps its full size. The band starts on an even row and ends on an
+ * odd one (or the last row): the filter transforms row pairs. Conservative: the whole detector when no bound
+ * exists (source distance inside the slab's circle), *row_count = 0 when the slab never projects onto the detector. */
+int paris_hip_slab_row_band(const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo,
+                            uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset, int enable_roi,
+                            const paris_region_of_interest* roi, uint32_t* row_first, uint32_t* row_count);
 /* angle of projection idx -> sin/cos on the host in fp32 (src/backprojection.cpp:52-63) */
 int paris_hip_stage_angle(const paris_detector_geometry* det_geo, uint32_t idx, int enable_angles, float phi,
                           float* sin_phi, float* cos_phi);

@@ -79,6 +79,7 @@ SIGNATURES = {
     "paris_hip_make_subvolume_information": (C.c_int, [_P(VolumeGeometry), _P(DetectorGeometry), C.c_int,
                                                        _P(SubvolumeInfo)]),
     "paris_hip_weight": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _f, _f, _f, _f, _f]),
+    "paris_hip_weight_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _f, _f, _f, _f, _f]),
     "paris_hip_make_filter": (C.c_int, [_vp, _u32, _f, _P(_vp)]),
     "paris_hip_apply_filter": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _u32, _u32]),
     "paris_hip_set_filter_variant": (C.c_int, [_vp, C.c_int]),
@@ -97,6 +98,10 @@ SIGNATURES = {
     "paris_hip_stage_weight": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _P(DetectorGeometry)]),
     "paris_hip_filter_size": (_u32, [_u32]),
     "paris_hip_stage_filter": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _P(DetectorGeometry)]),
+    "paris_hip_stage_weight_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _P(DetectorGeometry)]),
+    "paris_hip_stage_filter_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _P(DetectorGeometry)]),
+    "paris_hip_slab_row_band": (C.c_int, [_P(DetectorGeometry), _P(VolumeGeometry), _u32, _u32, _u32, _u32, C.c_int,
+                                          _P(RegionOfInterest), _P(_u32), _P(_u32)]),
     "paris_hip_stage_angle": (C.c_int, [_P(DetectorGeometry), _u32, C.c_int, _f, _P(_f), _P(_f)]),
     "paris_hip_stage_backproject": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _f, _vp, _u32, _u32, _u32, _u32,
                                               _P(DetectorGeometry), _P(VolumeGeometry), C.c_int, C.c_int,

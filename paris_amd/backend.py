@@ -358,6 +358,28 @@ def filter(backend, p, det_geo):  # noqa: A001 - the reference's name
           "paris_hip_stage_filter")
 
 
+def slab_row_band(det_geo, vol_geo, v_dim_x, v_dim_y, v_dim_z, v_offset=0, roi=None):
+    """f4: (first row, row count) of the detector band the slab can read (paris_hip_slab_row_band)."""
+    r = roi if roi is not None else RegionOfInterest()
+    first, count = C.c_uint32(), C.c_uint32()
+    check(_lib.load().paris_hip_slab_row_band(C.byref(det_geo), C.byref(vol_geo), v_dim_x, v_dim_y, v_dim_z, v_offset,
+                                              int(roi is not None), C.byref(r), C.byref(first), C.byref(count)),
+          "paris_hip_slab_row_band")
+    return first.value, count.value
+
+
+def weight_rows(backend, p, det_geo, row_first, row_count):
+    """paris::weight on the rows of a band only (paris_hip_stage_weight_rows)"""
+    check(backend._L.paris_hip_stage_weight_rows(backend._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, row_first, row_count,
+                                                 C.byref(det_geo)), "paris_hip_stage_weight_rows")
+
+
+def filter_rows(backend, p, det_geo, row_first, row_count):
+    """paris::filter on the rows of a band only (paris_hip_stage_filter_rows)"""
+    check(backend._L.paris_hip_stage_filter_rows(backend._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, row_first, row_count,
+                                                 C.byref(det_geo)), "paris_hip_stage_filter_rows")
+
+
 def backproject(backend, p, v, v_offset, det_geo, vol_geo, enable_angles, enable_roi, roi):
     """paris::backproject (src/backprojection.cpp:37-69)"""
     r = roi if roi is not None else RegionOfInterest()

@@ -9,7 +9,7 @@
 namespace
 {
     __global__ void __launch_bounds__(256)
-        weight_kernel(float* p, uint32_t pitch_f, uint32_t dim_x, uint32_t dim_y, float h_min, float v_min,
+        weight_kernel(float* p, uint32_t pitch_f, uint32_t dim_x, uint32_t row_first, uint32_t row_end, float h_min, float v_min,
                       float d_sd, float l_px_row, float l_px_col)
     {
         const uint32_t s = blockIdx.x * 256u + threadIdx.x;
@@ -19,7 +19,7 @@ namespace
         const float h_s = (l_px_row / 2) + s_f * l_px_row + h_min; // src/openmp/weighting.cpp:48
         const float hh = h_s * h_s;
         const float dd = d_sd * d_sd;
-        for(uint32_t t = blockIdx.y; t < dim_y; t += gridDim.y)
+        for(uint32_t t = row_first + blockIdx.y; t < row_end; t += gridDim.y)
         {
             const float t_f = static_cast<float>(t);
             const float v_t = (l_px_col / 2) + t_f * l_px_col + v_min; // :49
@@ -30,17 +30,25 @@ namespace
     }
 }
 
-extern "C" int paris_hip_weight(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
-                                float h_min, float v_min, float d_sd, float l_px_row, float l_px_col)
+extern "C" int paris_hip_weight_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                                     uint32_t row_first, uint32_t row_count, float h_min, float v_min, float d_sd,
+                                     float l_px_row, float l_px_col)
 {
     if(int rc = paris_hip_bind(ctx))
         return rc;
-    if(d_p == nullptr || pitch < static_cast<size_t>(dim_x) * sizeof(float) || pitch % sizeof(float) != 0)
+    if(d_p == nullptr || pitch < static_cast<size_t>(dim_x) * sizeof(float) || pitch % sizeof(float) != 0
+       || row_first > dim_y || row_count > dim_y - row_first)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    if(dim_x == 0 || dim_y == 0)
+    if(dim_x == 0 || row_count == 0)
         return paris_hip_finish(ctx);
-    const dim3 grid((dim_x + 255u) / 256u, dim_y < 65535u ? dim_y : 65535u);
+    const dim3 grid((dim_x + 255u) / 256u, row_count < 65535u ? row_count : 65535u);
     hipLaunchKernelGGL(weight_kernel, grid, dim3(256), 0, ctx->stream, d_p, static_cast<uint32_t>(pitch / sizeof(float)),
-                       dim_x, dim_y, h_min, v_min, d_sd, l_px_row, l_px_col);
+                       dim_x, row_first, row_first + row_count, h_min, v_min, d_sd, l_px_row, l_px_col);
     return paris_hip_finish(ctx);
+}
+
+extern "C" int paris_hip_weight(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                                float h_min, float v_min, float d_sd, float l_px_row, float l_px_col)
+{
+    return paris_hip_weight_rows(ctx, d_p, pitch, dim_x, dim_y, 0u, dim_y, h_min, v_min, d_sd, l_px_row, l_px_col);
 }

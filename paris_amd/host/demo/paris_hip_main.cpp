@@ -4,7 +4,7 @@
 //
 //   paris.hip --geometry geo.ini --input <dir> --output <dir> [--name vol] [--angles file] [--quality q]
 //             [--roi --roi-x1 a --roi-x2 b --roi-y1 c --roi-y2 d --roi-z1 e --roi-z2 f]
-//             [--slabs n] [--devices n] [--f16]
+//             [--slabs n] [--devices n] [--f16] [--no-row-band] [--drain-chunk-kib n]
 // geo.ini: key=value lines for n_row n_col l_px_row l_px_col delta_s delta_t d_so d_od delta_phi (:83-91).
 #include <cstdio>
 #include <cstdlib>
@@ -88,6 +88,8 @@ int main(int argc, char** argv)
             else if(k == "--slabs") po.slabs = std::stoi(val());
             else if(k == "--devices") po.devices = std::stoi(val());
             else if(k == "--f16") po.f16 = true;
+            else if(k == "--no-row-band") po.row_band = false;
+            else if(k == "--drain-chunk-kib") po.drain_chunk_bytes = static_cast<std::size_t>(std::stoull(val())) << 10;
             else throw paris::stage_construction_error{"unknown option " + k};
         }
         if(geometry.empty())
@@ -106,8 +108,9 @@ int main(int argc, char** argv)
                     r.info.num == 1 ? "" : "s", r.output_file.c_str(), r.wall_s);
         for(const auto& d : r.devices)
         {
-            std::printf("device %d: %u task(s), %u projections; host: source %.3f s, enqueue %.3f s, drain+D2H %.3f s, save %.3f s\n", d.device,
-                        d.tasks, d.projections, d.source_s, d.enqueue_s, d.drain_s, d.save_s);
+            std::printf("device %d: %u task(s), %u projections, %.0f detector rows per projection; host: source %.3f s, enqueue %.3f s, "
+                        "drain+D2H %.3f s, save %.3f s\n", d.device, d.tasks, d.projections,
+                        d.tasks ? static_cast<double>(d.band_rows) / d.tasks : 0.0, d.source_s, d.enqueue_s, d.drain_s, d.save_s);
             for(const auto& s : d.skipped)
                 std::printf("  skipped invalid file %s\n", s.c_str());
         }

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "paris/ddbvf.h"
 #include "paris/his.h"
@@ -98,6 +99,38 @@ int paris_io_source_scan(const char* dir, int enable_angles, const char* angle_f
                 idx_out[n] = p.idx;
                 phi_out[n] = p.phi;
                 first_pixel_out[n] = p.pixels.empty() ? 0.f : p.pixels[0];
+            }
+            ++n;
+        }
+        *n_frames = n;
+        *n_skipped = static_cast<uint32_t>(src.skipped_files().size());
+        return 0;
+    }
+    catch(const std::exception&) { return 1; }
+}
+// the same scan through frame_stream: frame i is written into data + i * dim_x * dim_y (caller-filled with a sentinel),
+// only rows [row_first, row_first + row_count). Frames of another size end the scan with return code 3.
+int paris_io_stream_scan(const char* dir, int enable_angles, const char* angle_file, uint16_t quality, uint32_t dim_x, uint32_t dim_y,
+                         uint32_t row_first, uint32_t row_count, uint32_t cap, uint32_t* n_frames, uint32_t* idx_out, float* phi_out,
+                         float* data, uint32_t* n_skipped)
+{
+    try
+    {
+        paris::frame_stream src{dir, enable_angles != 0, angle_file ? angle_file : "", quality};
+        auto scratch = std::vector<float>(static_cast<size_t>(dim_x) * dim_y);
+        uint32_t n = 0;
+        for(;;)
+        {
+            float* dst = n < cap ? data + static_cast<size_t>(n) * dim_x * dim_y : scratch.data();
+            const auto info = src.next(dst, dim_x, dim_y, row_first, row_count);
+            if(!info.valid())
+                break;
+            if(info.dim_x != dim_x || info.dim_y != dim_y)
+                return 3;
+            if(n < cap)
+            {
+                idx_out[n] = info.idx;
+                phi_out[n] = info.phi;
             }
             ++n;
         }

@@ -63,16 +63,6 @@ namespace paris
             template <typename T>
             void put(std::FILE* f, const T& v) { if(std::fwrite(&v, sizeof(T), 1, f) != 1) throw std::system_error{errno, std::generic_category()}; }
 
-            template <typename T>
-            bool read_as_float(std::FILE* f, float* dst, std::size_t n)
-            {
-                auto tmp = std::vector<T>(n);
-                const bool ok = std::fread(tmp.data(), sizeof(T), n, f) == n; // a short read leaves the tail as is
-                for(std::size_t i = 0; i < n; ++i)
-                    dst[i] = static_cast<float>(tmp[i]); // std::copy's implicit conversion: src/his.cpp:99
-                return ok;
-            }
-
             inline bool read_header(std::FILE* f, header& h)
             {
                 std::uint8_t rest[34];
@@ -83,51 +73,143 @@ namespace paris
             }
         }
 
+        // Frame-at-a-time reader with the acceptance rules of src/his.cpp:105-198. load() below is built on it; the
+        // pipelined driver uses it directly to convert a frame (or only a band of its rows) straight into its pinned
+        // upload buffer, without the intermediate copy the reference's reader makes.
+        class reader
+        {
+        public:
+            explicit reader(const std::string& path) : f_{std::fopen(path.c_str(), "rb")}
+            {
+                if(!f_)
+                    throw std::system_error{errno, std::generic_category(), "his::load(): cannot open " + path};
+                h_.file_type = 0;
+                h_.header_size = 0;
+                detail::read_header(f_.get(), h_); // a short header leaves the id / size checks to fail below
+                accepted_ = h_.file_type == file_id                              // :130-134
+                            && h_.header_size == file_header_size                // :135-139
+                            && h_.number_type != static_cast<std::uint16_t>(-1); // :140-144
+                const auto width = static_cast<std::uint32_t>(h_.brx) - static_cast<std::uint32_t>(h_.ulx) + 1u; // :146-151
+                const auto height = static_cast<std::uint32_t>(h_.bry) - static_cast<std::uint32_t>(h_.uly) + 1u;
+                dim_x_ = width;
+                dim_y_ = height;
+                // the reference reads (u16)width * (u16)height elements into a width * height buffer
+                n_ = static_cast<std::size_t>(static_cast<std::uint16_t>(width)) * static_cast<std::uint16_t>(height);
+                switch(h_.number_type) // :166-191
+                {
+                    case type_uchar: px_ = 1; break;
+                    case type_ushort: px_ = 2; break;
+                    case type_dword: px_ = 4; break;
+                    case type_double: px_ = 8; break;
+                    case type_float: px_ = 4; break;
+                    default: px_ = 0; break; // unsupported type: no (further) frames (:188-190)
+                }
+            }
+
+            auto head() const noexcept -> const header& { return h_; }
+            auto dim_x() const noexcept -> std::uint32_t { return dim_x_; }
+            auto dim_y() const noexcept -> std::uint32_t { return dim_y_; }
+
+            // Moves to the next frame; false when the file holds no further readable frame.
+            bool advance()
+            {
+                if(in_frame_)
+                    skip_payload();
+                if(!accepted_ || px_ == 0 || next_ >= h_.frame_number)
+                    return false;
+                if(h_.image_header_size) // skipped before every frame: :155-159 (Q14)
+                {
+                    skip_.resize(h_.image_header_size);
+                    if(std::fread(skip_.data(), 1, skip_.size(), f_.get()) != skip_.size())
+                    {
+                        accepted_ = false; // truncated file
+                        return false;
+                    }
+                }
+                ++next_;
+                in_frame_ = true;
+                return true;
+            }
+
+            // Converts rows [row_first, row_first + row_count) of the current frame into dst (dim_x * dim_y floats, row
+            // stride dim_x); other rows of dst are left untouched. Elements the file no longer holds read as 0.
+            void read_rows(float* dst, std::uint32_t row_first, std::uint32_t row_count)
+            {
+                if(!in_frame_)
+                    return;
+                const auto total = static_cast<std::size_t>(dim_x_) * dim_y_;
+                auto a = static_cast<std::size_t>(row_first) * dim_x_;
+                auto b = a + static_cast<std::size_t>(row_count) * dim_x_;
+                a = a < total ? a : total;
+                b = b < total ? b : total;
+                const auto stored_b = b < n_ ? b : n_; // elements beyond n_ are not in the file: they stay 0
+                const auto stored_a = a < stored_b ? a : stored_b;
+                const auto count = stored_b - stored_a;
+                raw_.resize(count * px_);
+                std::size_t got = 0;
+                if(count && std::fseek(f_.get(), static_cast<long>(stored_a * px_), SEEK_CUR) == 0)
+                    got = std::fread(raw_.data(), px_, count, f_.get());
+                consumed_ = stored_a * px_ + got * px_;
+                if(got < count)
+                    std::memset(raw_.data() + got * px_, 0, (count - got) * px_); // a short read leaves zeros (:99)
+                float* out = dst + stored_a;
+                switch(h_.number_type)
+                {
+                    case type_uchar: convert<std::uint8_t>(out, count); break;
+                    case type_ushort: convert<std::uint16_t>(out, count); break;
+                    case type_dword: convert<std::uint32_t>(out, count); break;
+                    case type_double: convert<double>(out, count); break;
+                    default: convert<float>(out, count); break;
+                }
+                for(auto i = stored_b; i < b; ++i)
+                    dst[i] = 0.f;
+                skip_payload();
+            }
+
+        private:
+            template <typename T>
+            void convert(float* out, std::size_t count) const
+            {
+                const auto* src = raw_.data();
+                for(std::size_t i = 0; i < count; ++i)
+                {
+                    T v;
+                    std::memcpy(&v, src + i * sizeof(T), sizeof(T));
+                    out[i] = static_cast<float>(v); // std::copy's implicit conversion: src/his.cpp:99
+                }
+            }
+
+            void skip_payload() // leaves the file position behind the current frame's pixels
+            {
+                const auto bytes = n_ * px_;
+                if(consumed_ < bytes)
+                    std::fseek(f_.get(), static_cast<long>(bytes - consumed_), SEEK_CUR); // past the end is fine: the next read fails
+                consumed_ = 0;
+                in_frame_ = false;
+            }
+
+            detail::file_ptr f_;
+            header h_{};
+            bool accepted_ = false, in_frame_ = false;
+            std::uint32_t dim_x_ = 0, dim_y_ = 0, next_ = 0;
+            std::size_t n_ = 0, px_ = 0, consumed_ = 0;
+            std::vector<std::uint8_t> skip_, raw_;
+        };
+
         // src/his.cpp:105-198. `out_header` (optional) receives the parsed file header.
         inline auto load(const std::string& path, header* out_header = nullptr) -> std::vector<frame>
         {
             auto frames = std::vector<frame>{};
-            auto f = detail::file_ptr{std::fopen(path.c_str(), "rb")};
-            if(!f)
-                throw std::system_error{errno, std::generic_category(), "his::load(): cannot open " + path};
-
-            auto h = header{};
-            h.file_type = 0;
-            h.header_size = 0;
-            detail::read_header(f.get(), h); // a short header leaves the id / size checks to fail below
+            auto r = reader{path};
             if(out_header)
-                *out_header = h;
-            if(h.file_type != file_id)            // :130-134
-                return frames;
-            if(h.header_size != file_header_size) // :135-139
-                return frames;
-            if(h.number_type == static_cast<std::uint16_t>(-1)) // :140-144
-                return frames;
-
-            const auto width = static_cast<std::uint32_t>(h.brx) - static_cast<std::uint32_t>(h.ulx) + 1u;  // :146-151
-            const auto height = static_cast<std::uint32_t>(h.bry) - static_cast<std::uint32_t>(h.uly) + 1u;
-            const auto n = static_cast<std::size_t>(static_cast<std::uint16_t>(width)) * static_cast<std::uint16_t>(height);
-            for(std::uint32_t i = 0; i < h.frame_number; ++i)
+                *out_header = r.head();
+            while(r.advance())
             {
-                if(h.image_header_size) // skipped before every frame: :155-159 (Q14)
-                {
-                    auto skip = std::vector<std::uint8_t>(h.image_header_size);
-                    if(std::fread(skip.data(), 1, skip.size(), f.get()) != skip.size())
-                        return frames; // truncated file
-                }
                 auto fr = frame{};
-                fr.dim_x = width;
-                fr.dim_y = height;
-                fr.pixels.assign(static_cast<std::size_t>(width) * height, 0.f);
-                switch(h.number_type) // :166-191
-                {
-                    case type_uchar: detail::read_as_float<std::uint8_t>(f.get(), fr.pixels.data(), n); break;
-                    case type_ushort: detail::read_as_float<std::uint16_t>(f.get(), fr.pixels.data(), n); break;
-                    case type_dword: detail::read_as_float<std::uint32_t>(f.get(), fr.pixels.data(), n); break;
-                    case type_double: detail::read_as_float<double>(f.get(), fr.pixels.data(), n); break;
-                    case type_float: detail::read_as_float<float>(f.get(), fr.pixels.data(), n); break;
-                    default: return frames; // unsupported type: what was read so far (:188-190)
-                }
+                fr.dim_x = r.dim_x();
+                fr.dim_y = r.dim_y();
+                fr.pixels.assign(static_cast<std::size_t>(fr.dim_x) * fr.dim_y, 0.f);
+                r.read_rows(fr.pixels.data(), 0, fr.dim_y);
                 frames.push_back(std::move(fr));
             }
             return frames;

@@ -44,6 +44,8 @@ namespace paris
         int devices = 0;   // 0: all
         int slots = 4;     // pinned upload buffers per device
         bool f16 = false;  // store filtered projections as IEEE half before backprojection (BASELINE config 5)
+        std::size_t drain_chunk_bytes = std::size_t{256} << 20; // pinned staging per buffer for the volume's way to the file
+        bool row_band = true; // f4: per slab, upload / weight / filter only the detector rows the slab can read
     };
 
     // src/task.h:33-57
@@ -94,6 +96,7 @@ namespace paris
     {
         int device = 0;
         std::uint32_t tasks = 0, projections = 0;
+        std::uint64_t band_rows = 0; // sum over tasks of the detector rows processed per projection (f4)
         double source_s = 0, enqueue_s = 0, drain_s = 0, save_s = 0;
         std::vector<std::string> skipped;
     };
@@ -127,7 +130,9 @@ namespace paris
         std::size_t d_pitch = 0, h16_pitch = 0;
         std::uint16_t* d_half = nullptr;
         float* d_v = nullptr;
-        float* h_v = nullptr;
+        float* h_stage[2] = {nullptr, nullptr}; // pinned staging for the drain: D2H of chunk k+1 overlaps the file write of chunk k
+        paris_hip_fence* stage_fence[2] = {nullptr, nullptr};
+        std::size_t stage_floats = 0;
         auto cleanup = [&] {
             for(int s = 0; s < slots; ++s)
             {
@@ -137,7 +142,11 @@ namespace paris
             }
             paris_hip_free(ctx, d_half);
             paris_hip_free(ctx, d_v);
-            paris_hip_free_host(ctx, h_v);
+            for(int s = 0; s < 2; ++s)
+            {
+                paris_hip_fence_destroy(ctx, stage_fence[s]);
+                paris_hip_free_host(ctx, h_stage[s]);
+            }
             paris_hip_ctx_destroy(ctx);
         };
         try
@@ -171,42 +180,72 @@ namespace paris
                 if(voxels > v_cap) // slabs of one run have (almost) the same size: allocate once, re-zero per task
                 {
                     rt(paris_hip_free(ctx, d_v), "free");
-                    rt(paris_hip_free_host(ctx, h_v), "free");
                     d_v = nullptr;
-                    h_v = nullptr;
                     rt(paris_hip_malloc_volume(ctx, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z, &d_v), "make_volume()");
-                    void* p = nullptr;
-                    rt(paris_hip_malloc_host(ctx, voxels * sizeof(float), &p), "make_volume_host()");
-                    h_v = static_cast<float*>(p);
                     v_cap = voxels;
                 }
                 else
                     rt(paris_hip_memset_volume(ctx, d_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z), "make_volume()");
+                // the host side of the slab is two pinned chunks of whole slices (the reference allocates the whole slab:
+                // src/sink.cpp:76); pinning gigabytes costs more than the reconstruction of a small data set
+                const auto slice_floats = static_cast<std::size_t>(t.subvol_geo.dim_x) * t.subvol_geo.dim_y;
+                const auto want_floats = std::max(slice_floats, std::min(voxels, po.drain_chunk_bytes / sizeof(float)) / slice_floats * slice_floats);
+                if(want_floats > stage_floats)
+                {
+                    for(int s = 0; s < 2; ++s)
+                    {
+                        rt(paris_hip_free_host(ctx, h_stage[s]), "free");
+                        h_stage[s] = nullptr;
+                        void* p = nullptr;
+                        rt(paris_hip_malloc_host(ctx, want_floats * sizeof(float), &p), "make_volume_host()");
+                        h_stage[s] = static_cast<float*>(p);
+                        if(stage_fence[s] == nullptr)
+                            rt(paris_hip_fence_create(ctx, &stage_fence[s]), "fence");
+                    }
+                    stage_floats = want_floats;
+                }
+
+                std::uint32_t band_first = 0, band_count = n_col;
+                if(po.row_band)
+                    rt(paris_hip_slab_row_band(&t.det_geo, &t.vol_geo, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z, offset, t.enable_roi,
+                                               &t.roi, &band_first, &band_count), "slab_row_band()");
+                rep.band_rows += band_count;
+                const auto row_bytes = static_cast<std::size_t>(n_row) * sizeof(float);
 
                 auto t0 = clock::now();
-                source src{t.input_path, t.enable_angles, t.angle_path, t.quality}; // :93 (index restarts per task)
+                frame_stream src{t.input_path, t.enable_angles, t.angle_path, t.quality}; // :93 (index restarts per task)
                 rep.source_s += since(t0);
                 int slot = 0;
-                while(!src.drained()) // :98
+                for(;;) // :98
                 {
                     t0 = clock::now();
-                    auto p = src.load_next(); // :100
+                    rt(paris_hip_fence_wait(ctx, fence[slot]), "fence wait"); // everything that last used this slot is done
+                    rep.enqueue_s += since(t0);
+                    // f4: only the detector rows this slab can read are converted, uploaded, weighted and filtered; the
+                    // buffers keep their full size, rows outside the band are never read for a voxel of the slab
+                    t0 = clock::now();
+                    const auto p = src.next(h_buf[slot], n_row, n_col, band_first, band_count); // :100, straight into pinned memory
                     rep.source_s += since(t0);
                     if(!p.valid())
                         break;
                     if(p.dim_x != n_row || p.dim_y != n_col)
                         throw stage_runtime_error{"projection size does not match the detector geometry"};
                     t0 = clock::now();
-                    rt(paris_hip_fence_wait(ctx, fence[slot]), "fence wait"); // everything that last used this slot is done
-                    std::memcpy(h_buf[slot], p.pixels.data(), frame_bytes);
+                    const auto band_off = static_cast<std::size_t>(band_first) * n_row;
+                    auto* d_band = reinterpret_cast<float*>(reinterpret_cast<char*>(d_buf[slot]) + static_cast<std::size_t>(band_first) * d_pitch);
                     // :101 -- on the upload stream, overlapping the kernels of the previous projections
-                    rt(paris_hip_upload_projection(ctx, d_buf[slot], d_pitch, h_buf[slot], static_cast<std::size_t>(n_row) * sizeof(float),
-                                                   n_row, n_col), "load()");
-                    rt(paris_hip_stage_weight(ctx, d_buf[slot], d_pitch, n_row, n_col, &t.det_geo), "weight()"); // :102
-                    rt(paris_hip_stage_filter(ctx, d_buf[slot], d_pitch, n_row, n_col, &t.det_geo), "filter()"); // :103
+                    if(band_count != 0)
+                    {
+                        rt(paris_hip_upload_projection(ctx, d_band, d_pitch, h_buf[slot] + band_off, row_bytes, n_row, band_count), "load()");
+                        rt(paris_hip_stage_weight_rows(ctx, d_buf[slot], d_pitch, n_row, n_col, band_first, band_count, &t.det_geo), "weight()"); // :102
+                        rt(paris_hip_stage_filter_rows(ctx, d_buf[slot], d_pitch, n_row, n_col, band_first, band_count, &t.det_geo), "filter()"); // :103
+                    }
                     if(po.f16)
                     {
-                        rt(paris_hip_convert_projection_f16(ctx, d_buf[slot], d_pitch, d_half, h16_pitch, n_row, n_col), "to half");
+                        if(band_count != 0)
+                            rt(paris_hip_convert_projection_f16(ctx, d_band, d_pitch,
+                                                                reinterpret_cast<std::uint16_t*>(reinterpret_cast<char*>(d_half) + static_cast<std::size_t>(band_first) * h16_pitch),
+                                                                h16_pitch, n_row, band_count), "to half");
                         const float delta_s = t.det_geo.delta_s * t.det_geo.l_px_row, delta_t = t.det_geo.delta_t * t.det_geo.l_px_col;
                         float sn = 0.f, cs = 0.f;
                         rt(paris_hip_stage_angle(&t.det_geo, p.idx, t.enable_angles, p.phi, &sn, &cs), "angle");
@@ -226,13 +265,31 @@ namespace paris
                 for(const auto& s : src.skipped_files())
                     rep.skipped.push_back(s);
 
+                // src/sink.cpp:76-82 in chunks of whole slices: copy chunk k+1 down while chunk k goes to the file
+                const auto chunk_z = static_cast<std::uint32_t>(stage_floats / slice_floats);
+                const auto n_chunks = (dim_z + chunk_z - 1u) / chunk_z;
+                const auto copy_down = [&](std::uint32_t c) {
+                    const auto z0 = c * chunk_z;
+                    const auto nz = std::min(chunk_z, dim_z - z0);
+                    rt(paris_hip_memcpy_volume_d2h(ctx, h_stage[c % 2u], d_v + static_cast<std::size_t>(z0) * slice_floats, t.subvol_geo.dim_x,
+                                                   t.subvol_geo.dim_y, nz), "copy_d2h()");
+                    rt(paris_hip_fence_record(ctx, stage_fence[c % 2u]), "fence record");
+                };
                 t0 = clock::now();
-                rt(paris_hip_memcpy_volume_d2h(ctx, h_v, d_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z), "copy_d2h()"); // src/sink.cpp:76-77
-                rt(paris_hip_ctx_synchronize(ctx), "synchronize");
+                copy_down(0);
                 rep.drain_s += since(t0);
-                t0 = clock::now();
-                out.save(h_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z, offset); // :107
-                rep.save_s += since(t0);
+                for(std::uint32_t c = 0; c < n_chunks; ++c)
+                {
+                    t0 = clock::now();
+                    if(c + 1u < n_chunks)
+                        copy_down(c + 1u); // its buffer was written to the file in the previous iteration
+                    rt(paris_hip_fence_wait(ctx, stage_fence[c % 2u]), "fence wait");
+                    rep.drain_s += since(t0);
+                    t0 = clock::now();
+                    const auto z0 = c * chunk_z;
+                    out.save(h_stage[c % 2u], t.subvol_geo.dim_x, t.subvol_geo.dim_y, std::min(chunk_z, dim_z - z0), offset + z0); // :107
+                    rep.save_s += since(t0);
+                }
                 ++rep.tasks;
             }
         }

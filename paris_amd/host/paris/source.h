@@ -167,6 +167,88 @@ namespace paris
         std::uint16_t quality_;
         std::uint32_t counter_ = 0;
     };
+    // Metadata of a frame that frame_stream::next() wrote into caller memory
+    struct frame_info
+    {
+        std::uint32_t dim_x = 0, dim_y = 0;
+        std::uint32_t idx = 0;
+        float phi = 0.f;
+        bool valid() const noexcept { return dim_x != 0 && dim_y != 0; }
+    };
+
+    // The same frames in the same order, with the same indices, stride and skipped files as `source`, but one at a time
+    // and converted straight into memory the caller owns (the driver's pinned upload slot): no per-file frame queue, no
+    // extra copy, and only the detector rows the caller asks for are read and converted (f4).
+    // Frames dropped by the quality stride are seeked over, not converted.
+    class frame_stream
+    {
+    public:
+        frame_stream(const std::string& proj_dir, bool enable_angles = false, const std::string& angle_file = "",
+                     std::uint16_t quality = 1)
+        : enable_angles_{enable_angles}, quality_{quality == 0 ? std::uint16_t{1} : quality}
+        {
+            paths_ = read_directory(proj_dir); // src/source.cpp:79
+            if(enable_angles_)
+                angles_ = read_angles(angle_file); // :83-84
+        }
+
+        auto skipped_files() const noexcept -> const std::vector<std::string>& { return skipped_; }
+
+        // Writes rows [row_first, row_first + row_count) of the next kept frame into dst (dim_x * dim_y floats, row
+        // stride dim_x) and returns its metadata; !valid() when the directory is exhausted. A frame whose size is not
+        // dim_x x dim_y is reported with its own size and nothing is written.
+        auto next(float* dst, std::uint32_t dim_x, std::uint32_t dim_y, std::uint32_t row_first, std::uint32_t row_count) -> frame_info
+        {
+            for(;;)
+            {
+                if(!reader_)
+                {
+                    if(next_path_ >= paths_.size())
+                        return frame_info{};
+                    const auto& path = paths_[next_path_++];
+                    try { reader_.reset(new his::reader{path}); }
+                    catch(const std::system_error&) { reader_.reset(); }
+                    frames_of_file_ = 0;
+                    if(!reader_)
+                    {
+                        skipped_.push_back(path); // "Skipping invalid file": :96-100
+                        continue;
+                    }
+                }
+                if(!reader_->advance())
+                {
+                    if(frames_of_file_ == 0)
+                        skipped_.push_back(paths_[next_path_ - 1]);
+                    reader_.reset();
+                    continue;
+                }
+                ++frames_of_file_;
+                const auto counter = counter_++;
+                if(counter % quality_ != 0u) // :105-113: the stride keeps the original index
+                    continue;                // advance() seeks over the unread frame
+                auto info = frame_info{};
+                info.dim_x = reader_->dim_x();
+                info.dim_y = reader_->dim_y();
+                info.idx = counter;
+                if(enable_angles_ && !angles_.empty())
+                    info.phi = angles_.at(counter);
+                if(info.dim_x == dim_x && info.dim_y == dim_y)
+                    reader_->read_rows(dst, row_first, row_count);
+                return info;
+            }
+        }
+
+    private:
+        std::vector<std::string> paths_;
+        std::size_t next_path_ = 0;
+        std::unique_ptr<his::reader> reader_;
+        std::uint32_t frames_of_file_ = 0;
+        std::vector<std::string> skipped_;
+        bool enable_angles_;
+        std::vector<float> angles_;
+        std::uint16_t quality_;
+        std::uint32_t counter_ = 0;
+    };
 }
 
 #endif

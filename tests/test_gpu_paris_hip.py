@@ -70,6 +70,17 @@ def test_his_to_ddbvf(tmp_path, oracle, slabs):
     assert_close(vol, oracle_volume(oracle, range(8)))
 
 
+@pytest.mark.parametrize("extra", [["--drain-chunk-kib", 40], ["--drain-chunk-kib", 1, "--slabs", 2], ["--no-row-band", "--slabs", 4]])
+def test_chunked_drain_and_row_band_switch(tmp_path, oracle, extra):
+    """The volume goes to the file through two pinned chunks of whole slices (67 x 67 floats = 17.5 KiB per slice: 40 KiB =
+    2 slices per chunk, 1 KiB = 1 slice); the detector row band (f4) can be switched off. Same volume either way."""
+    geo = write_dataset(oracle, tmp_path / "in")
+    run(["--geometry", geo, "--input", tmp_path / "in", "--output", tmp_path / "out", "--name", "kat"] + extra)
+    head, vol = F.ddbvf_read(str(tmp_path / "out" / "kat.ddbvf"))
+    assert head == F.ddbvf_header_bytes(67, 67, 61)
+    assert_close(vol, oracle_volume(oracle, range(8)))
+
+
 def test_roi_quality_and_angles(tmp_path, oracle):
     geo = write_dataset(oracle, tmp_path / "in", files=(8,))
     ang = tmp_path / "angles.txt"

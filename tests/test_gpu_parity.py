@@ -561,6 +561,84 @@ def test_pipeline_against_oracle(be, oracle, kat_golden):
     be.free(d_v)
 
 
+def test_row_band_pipeline_is_bit_identical_to_the_full_projection(be, oracle):
+    """f4: upload + weight + filter only the slab's detector band (paris_hip_slab_row_band, *_rows entry points); the
+    band's pixels and the slab volume must equal the full-projection run bit for bit. Rows outside the band hold NaN."""
+    g = (200, 180, 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 11.25)
+    det = B.DetectorGeometry(*g)
+    vg = B.calculate_volume_geometry(det)
+    n_slabs = 6
+    dz = vg.dim_z // n_slabs
+    seen_partial = 0
+    for variant in (0, 1):  # radix-16 register filter is used from N = 1024 up; N = 512 here takes the radix-2 kernel either way
+        be.set_filter_variant(variant)
+        for slab in range(n_slabs):
+            v_offset = slab * dz
+            first, count = B.slab_row_band(det, vg, vg.dim_x, vg.dim_y, dz, v_offset)
+            assert count > 0
+            seen_partial += count < det.n_col
+            d_full = be.make_volume_device(vg.dim_x, vg.dim_y, dz)
+            d_band = be.make_volume_device(vg.dim_x, vg.dim_y, dz)
+            for i in range(4):
+                raw = oracle.lcg_projection(200, 180, i)
+                d_p = to_device(be, raw, idx=i)
+                B.weight(be, d_p, det)
+                B.filter(be, d_p, det)
+                B.backproject(be, d_p, d_full, v_offset, det, vg, False, False, None)
+                full_pixels = to_host(be, d_p)
+                be.free(d_p)
+                poisoned = np.full_like(raw, np.nan)
+                poisoned[first:first + count] = raw[first:first + count]
+                d_q = to_device(be, poisoned, idx=i)
+                B.weight_rows(be, d_q, det, first, count)
+                B.filter_rows(be, d_q, det, first, count)
+                band_pixels = to_host(be, d_q)
+                assert np.array_equal(band_pixels[first:first + count].view(np.uint32),
+                                      full_pixels[first:first + count].view(np.uint32))
+                assert np.isnan(band_pixels[:first]).all() and np.isnan(band_pixels[first + count:]).all()
+                B.backproject(be, d_q, d_band, v_offset, det, vg, False, False, None)
+                be.free(d_q)
+            assert_bit_equal(volume_to_host(be, d_band), volume_to_host(be, d_full))
+            be.free(d_full)
+            be.free(d_band)
+    be.set_filter_variant(0)
+    assert seen_partial >= 8
+
+
+def test_row_band_with_the_register_filter(be, oracle):
+    """Same on a 1024-wide detector (N = 2048: the radix-16 register-pass filter), one thin slab off centre."""
+    det = B.DetectorGeometry(1024, 256, 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 30.0)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(256, 256, nat.dim_z, nat.l_vx_x * 4, nat.l_vx_y * 4, nat.l_vx_z)
+    dz, v_offset = 24, nat.dim_z // 2 + 40
+    first, count = B.slab_row_band(det, vg, 256, 256, dz, v_offset)
+    assert 0 < count < 128
+    d_full = be.make_volume_device(256, 256, dz)
+    d_band = be.make_volume_device(256, 256, dz)
+    for i in range(3):
+        raw = oracle.lcg_projection(1024, 256, i)
+        d_p = to_device(be, raw, idx=i)
+        B.weight(be, d_p, det)
+        B.filter(be, d_p, det)
+        B.backproject(be, d_p, d_full, v_offset, det, vg, False, False, None)
+        full_pixels = to_host(be, d_p)
+        be.free(d_p)
+        poisoned = np.full_like(raw, np.nan)
+        poisoned[first:first + count] = raw[first:first + count]
+        d_q = to_device(be, poisoned, idx=i)
+        B.weight_rows(be, d_q, det, first, count)
+        B.filter_rows(be, d_q, det, first, count)
+        assert np.array_equal(to_host(be, d_q)[first:first + count].view(np.uint32),
+                              full_pixels[first:first + count].view(np.uint32))
+        B.backproject(be, d_q, d_band, v_offset, det, vg, False, False, None)
+        be.free(d_q)
+    got = volume_to_host(be, d_band)
+    assert np.abs(got).max() > 0
+    assert_bit_equal(got, volume_to_host(be, d_full))
+    be.free(d_full)
+    be.free(d_band)
+
+
 def test_config1_shepp_logan_256_cube(be, oracle):
     """BASELINE config 1: 256^3 volume (voxels twice the natural size), 360 projections @ 512x512 of the analytic 3-D
     Shepp-Logan phantom, the case the reference's OpenMP backend is quoted on. GPU pipeline vs oracle pipeline to the
@@ -743,6 +821,19 @@ def test_backproject_random_geometries_bit_exact(be, oracle, seed):
         be.free(d_p)
     assert_bit_equal(volume_to_host(be, d_v), want)
     be.free(d_v)
+
+    # f4: rows outside paris_hip_slab_row_band never reach the slab -- poison them with NaN
+    first, count = B.slab_row_band(det, vg, dims[2], dims[1], dims[0], v_offset, roi)
+    if count < n_col:
+        d_v = be.make_volume_device(dims[2], dims[1], dims[0])
+        for i, p in enumerate(projs):
+            q = np.full_like(p, np.nan)
+            q[first:first + count] = p[first:first + count]
+            d_p = to_device(be, q, idx=i, phi=angles[i])
+            B.backproject(be, d_p, d_v, v_offset, det, vg, True, use_roi, roi)
+            be.free(d_p)
+        assert_bit_equal(volume_to_host(be, d_v), want)
+        be.free(d_v)
 
     if dims[2] % 4 == 0:  # the fused batch entry on the same case
         stack = be.make_projection_device(n_row, n_col * n_proj)

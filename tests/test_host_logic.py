@@ -155,3 +155,82 @@ def test_reference_wrappers_compile_against_the_hip_backend(tmp_path):
     r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-DPARIS_ENABLE_HIP", "-DPARIS_HIP_INSIDE_PARIS", "-I",
                         os.path.join(ROOT, "include"), str(probe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def _rows_touched(det, vg, dims, v_offset, roi, sin, cos):
+    """fp32 restatement of the v coordinate of src/openmp/backprojection.cpp:116-133: (lowest, highest) detector row any
+    valid tap of the slab reads for this angle, or None."""
+    f32 = np.float32
+    dz, dy, dx = dims
+    rx, ry, rz = (roi.x1, roi.y1, roi.z1) if roi is not None else (0, 0, 0)
+
+    def centred(coord, dim, size):
+        size2 = f32(size) / f32(2)
+        return -(f32(dim) * size2) + size2 + coord.astype(f32) * f32(size)
+
+    x = centred(np.arange(dx) + rx, vg.dim_x, vg.l_vx_x)[None, :]
+    y = centred(np.arange(dy) + ry, vg.dim_y, vg.l_vx_y)[:, None]
+    z = centred(np.array([0, dz - 1]) + rz + v_offset, vg.dim_z, vg.l_vx_z)
+    s = x * f32(cos) + y * f32(sin)
+    factor = (f32(abs(det.d_so)) + f32(abs(det.d_od))) / (s + f32(det.d_so))
+    size2 = f32(det.l_px_col) / f32(2)
+    vmin = -(f32(det.n_col) * size2) - f32(det.delta_t) * f32(det.l_px_col)
+    lo, hi = None, None
+    for zz in z:  # v is monotonic in z for a fixed column: the end slices bound every slice in between
+        v = (zz * factor - vmin) / f32(det.l_px_col) - f32(0.5)
+        v1 = np.floor(v)
+        ok = (v1 >= 0) & (v1 + 1 < det.n_col)
+        if ok.any():
+            a, b = int(v1[ok].min()), int(v1[ok].max()) + 1
+            lo = a if lo is None else min(lo, a)
+            hi = b if hi is None else max(hi, b)
+    return None if lo is None else (lo, hi)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_slab_row_band_covers_every_tap(seed):
+    """f4: paris_hip_slab_row_band must contain every detector row a valid tap of the slab reads, for any angle; for a
+    slab whose end slices straddle the band the bound must also be useful (not the whole detector for thin slabs)."""
+    rng = np.random.default_rng(7000 + seed)
+    n_row, n_col = int(rng.integers(24, 300)), int(rng.integers(16, 300))
+    l_r, l_c = float(rng.choice([0.1, 0.2, 0.127, 0.4])), float(rng.choice([0.1, 0.2, 0.25, 0.4]))
+    d_so, d_od = float(rng.uniform(40, 600)), float(rng.uniform(20, 600))
+    det = B.DetectorGeometry(n_row, n_col, l_r, l_c, float(rng.uniform(-6, 6)), float(rng.uniform(-6, 6)), d_so, d_od, 1.0)
+    nat = B.calculate_volume_geometry(det)
+    full = [int(rng.integers(20, 160)) for _ in range(3)]  # z, y, x
+    scale = [float(nat.l_vx_x * rng.uniform(0.4, 2.5)) for _ in range(3)]
+    half_diag = 0.5 * np.hypot(full[2] * scale[0], full[1] * scale[1])
+    if half_diag > 0.8 * d_so:
+        scale[0] *= 0.8 * d_so / half_diag
+        scale[1] *= 0.8 * d_so / half_diag
+    vg = B.VolumeGeometry(full[2], full[1], full[0], *scale)
+    roi = None
+    out = tuple(full)
+    if seed % 2:
+        x1, y1, z1 = (int(rng.integers(1, d // 3)) for d in (full[2], full[1], full[0]))
+        x2, y2, z2 = (int(rng.integers(2 * d // 3, d)) for d in (full[2], full[1], full[0]))
+        roi = B.RegionOfInterest(x1, x2, y1, y2, z1, z2)
+        out = (z2 - z1, y2 - y1, x2 - x1)
+    n_slabs = int(rng.integers(1, 9))
+    dz = max(1, out[0] // n_slabs)
+    for g in range(n_slabs):
+        v_offset = g * dz
+        dims = (dz if g < n_slabs - 1 else out[0] - v_offset, out[1], out[2])
+        first, count = B.slab_row_band(det, vg, dims[2], dims[1], dims[0], v_offset, roi)
+        assert first % 2 == 0 and first + count <= n_col and (count == 0 or (first + count) % 2 == 0 or first + count == n_col)
+        lo, hi = None, None
+        for phi in list(rng.uniform(0, 2 * np.pi, 12)) + [0.0, np.pi / 4, np.pi / 2, 3 * np.pi / 4, np.pi]:
+            r = _rows_touched(det, vg, dims, v_offset, roi, np.float32(np.sin(phi)), np.float32(np.cos(phi)))
+            if r is not None:
+                lo = r[0] if lo is None else min(lo, r[0])
+                hi = r[1] if hi is None else max(hi, r[1])
+        if lo is None:
+            continue
+        assert first <= lo and hi < first + count, (seed, g, (first, count), (lo, hi))
+    # the z-slabs of the whole field of view at the bench geometry: the band is a fraction of the detector
+    det = B.DetectorGeometry(2048, 2048, 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 0.25)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(2048, 2048, 2048, *([float(np.float32(nat.l_vx_x))] * 3))
+    counts = [B.slab_row_band(det, vg, 2048, 2048, 256, 256 * g)[1] for g in range(8)]
+    assert max(counts) < 0.4 * 2048 and counts == counts[::-1]
+    assert B.slab_row_band(det, vg, 2048, 2048, 2048, 0) == (0, 2048)

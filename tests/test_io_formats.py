@@ -150,3 +150,51 @@ def test_source_order_stride_and_skips(io, tmp_path):
     assert idx == [0, 2, 4] and first == [0, 2, 4] and phi == [0.0, 20.0, 40.0]
     idx, _, _, _ = scan(4, False)
     assert idx == [0, 4]
+
+
+@pytest.mark.parametrize("number_type", [2, 4, 32, 64, 128])
+@pytest.mark.parametrize("image_header", [0, 32])
+def test_frame_stream_equals_the_queueing_source(io, tmp_path, number_type, image_header):
+    """frame_stream (one frame at a time into caller memory, optional row band, stride frames seeked over) hands out
+    exactly the frames, indices, angles and skipped files of the reference-shaped source, and touches only the band."""
+    io.paris_io_stream_scan.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_uint32, _u32p, _u32p, _fp, _fp, _u32p]
+    rng = np.random.default_rng(number_type + image_header)
+    d = tmp_path / "proj"
+    d.mkdir()
+    w, h = 7, 10
+    frames = []
+    for name, n in (("a.his", 3), ("b.his", 1), ("c.his", 4)):
+        fr = rng.integers(0, 250, size=(n, h, w)).astype(np.float32)
+        frames += list(fr)
+        (d / name).write_bytes(F.his_file_bytes(fr, number_type, image_header))
+    (d / "b_broken.his").write_bytes(b"\x00" * 100)            # wrong id: skipped
+    truncated = F.his_file_bytes(rng.integers(0, 250, size=(2, h, w)).astype(np.float32), number_type, image_header)
+    cut = len(truncated) - (w * h * {2: 1, 4: 2, 32: 4, 64: 8, 128: 4}[number_type]) // 2 - 3
+    (d / "d_truncated.his").write_bytes(truncated[:cut])       # second frame half there: zeros for the missing pixels
+    want_tail = his_load(io, d / "d_truncated.his")
+    assert len(want_tail) == 2 and np.any(want_tail[1] != 0) and want_tail[1][-1, -1] == 0
+    frames += want_tail
+    ang = tmp_path / "ang.txt"
+    ang.write_text(" ".join(str(3.0 * i) for i in range(len(frames))))
+
+    for quality in (1, 2, 3):
+        for first, count in ((0, h), (2, 5), (9, 1), (4, 0)):
+            cap = 16
+            n, skipped = C.c_uint32(), C.c_uint32()
+            idx = (C.c_uint32 * cap)()
+            phi = (C.c_float * cap)()
+            data = np.full((cap, h, w), -7.0, np.float32)
+            rc = io.paris_io_stream_scan(str(d).encode(), 1, str(ang).encode(), quality, w, h, first, count, cap, C.byref(n), idx,
+                                         phi, data.ctypes.data_as(_fp), C.byref(skipped))
+            assert rc == 0 and skipped.value == 1
+            keep = list(range(0, len(frames), quality))
+            assert list(idx[:n.value]) == keep
+            assert list(phi[:n.value]) == [np.float32(3.0 * i) for i in keep]
+            for j, i in enumerate(keep):
+                assert np.array_equal(data[j, first:first + count], frames[i][first:first + count])
+                assert np.all(data[j, :first] == -7.0) and np.all(data[j, first + count:] == -7.0)
+    # a frame of another size is reported, not written
+    rc = io.paris_io_stream_scan(str(d).encode(), 0, None, 1, w + 1, h, 0, h, 0, C.byref(n), idx, phi, data.ctypes.data_as(_fp),
+                                 C.byref(skipped))
+    assert rc == 3
