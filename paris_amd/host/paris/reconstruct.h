@@ -8,6 +8,9 @@
 //     converts the next HIS frame into one of `slots` pinned upload buffers (each slot = pinned host + device buffer,
 //     guarded by a stream fence recorded after its backprojection); the upload runs on a second stream and the
 //     compute stream waits for it by event, so file I/O, PCIe upload and GPU work all overlap;
+//   - per slab only the detector rows it can read are converted, uploaded, weighted and filtered (8f-4,
+//     paris_hip_slab_row_band); the slab reaches the file through two pinned chunks (D2H of one overlapping the write
+//     of the other) instead of a pinned copy of the whole slab;
 //   - geometry constants are derived per call and the slab offset is passed per task (Q1, Q2), the source restarts
 //     its frame index per task (Q5), slabs are written at their own slice offset (Q4);
 //   - slab planning is 64-bit and memory driven (paris_hip_make_subvolume_information) with an optional fixed count.
