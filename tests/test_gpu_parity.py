@@ -765,6 +765,9 @@ def test_config3_4_geometry_slab_crops(be, oracle):
     be.free(stack)
 
 
+BAND_STATS = {"cases": 0, "partial": 0}
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PARIS_FUZZ_SEEDS", "24"))))
 def test_backproject_random_geometries_bit_exact(be, oracle, seed):
     """Seeded random geometries: detector size and pitch, offsets of either sign, source / detector distances from a
@@ -822,17 +825,22 @@ def test_backproject_random_geometries_bit_exact(be, oracle, seed):
     assert_bit_equal(volume_to_host(be, d_v), want)
     be.free(d_v)
 
-    # f4: rows outside paris_hip_slab_row_band never reach the slab -- poison them with NaN
-    first, count = B.slab_row_band(det, vg, dims[2], dims[1], dims[0], v_offset, roi)
+    # f4: rows outside paris_hip_slab_row_band never reach the slab -- poison them with NaN. A thin sub-slab, so that
+    # the band is a real subset of the detector in most cases.
+    dz2 = max(1, dims[0] // int(rng.integers(3, 9)))
+    z2 = int(rng.integers(0, dims[0] - dz2 + 1))
+    first, count = B.slab_row_band(det, vg, dims[2], dims[1], dz2, v_offset + z2, roi)
+    BAND_STATS["cases"] += 1
     if count < n_col:
-        d_v = be.make_volume_device(dims[2], dims[1], dims[0])
+        BAND_STATS["partial"] += 1
+        d_v = be.make_volume_device(dims[2], dims[1], dz2)
         for i, p in enumerate(projs):
             q = np.full_like(p, np.nan)
             q[first:first + count] = p[first:first + count]
             d_p = to_device(be, q, idx=i, phi=angles[i])
-            B.backproject(be, d_p, d_v, v_offset, det, vg, True, use_roi, roi)
+            B.backproject(be, d_p, d_v, v_offset + z2, det, vg, True, use_roi, roi)
             be.free(d_p)
-        assert_bit_equal(volume_to_host(be, d_v), want)
+        assert_bit_equal(volume_to_host(be, d_v), want[z2:z2 + dz2])
         be.free(d_v)
 
     if dims[2] % 4 == 0:  # the fused batch entry on the same case
@@ -845,6 +853,11 @@ def test_backproject_random_geometries_bit_exact(be, oracle, seed):
         assert_bit_equal(volume_to_host(be, d_v), want)
         be.free(d_v)
         be.free(stack)
+
+
+def test_random_geometries_exercised_partial_row_bands():
+    """Runs after the fuzz above: the NaN-poison pass must have met real sub-bands, not only whole detectors."""
+    assert BAND_STATS["cases"] > 0 and BAND_STATS["partial"] >= BAND_STATS["cases"] // 3, BAND_STATS
 
 
 def test_empty_and_degenerate_arguments(be, oracle, kat_golden):
