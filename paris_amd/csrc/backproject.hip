@@ -1201,8 +1201,9 @@ extern "C" int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p,
 
     // The fused kernel needs 16-byte lanes; any other volume, and the cross-check variants, take the sequence of
     // single-projection launches that the fused kernel is defined to equal.
-    const bool fused_ok = (ctx->bp_variant == 0 || ctx->bp_variant == 4) && d_v != nullptr && lane_width(d_v, v_dim_x) == 4
-                          && (ctx->bp_vx == 0 || ctx->bp_vx == 4);
+    // A single projection is the tile kernel's case (memory bound, nothing to fuse).
+    const bool fused_ok = n_proj > 1 && (ctx->bp_variant == 0 || ctx->bp_variant == 4) && d_v != nullptr
+                          && lane_width(d_v, v_dim_x) == 4 && (ctx->bp_vx == 0 || ctx->bp_vx == 4);
     if(!fused_ok)
     {
         const unsigned saved = ctx->flags;

@@ -47,6 +47,7 @@ namespace paris
         int devices = 0;   // 0: all
         int slots = 4;     // pinned upload buffers per device
         bool f16 = false;  // store filtered projections as IEEE half before backprojection (BASELINE config 5)
+        int batch = 8;     // projections per fused backprojection launch (1: one launch per projection, as the reference)
         std::size_t drain_chunk_bytes = std::size_t{256} << 20; // pinned staging per buffer for the volume's way to the file
         bool row_band = true; // f4: per slab, upload / weight / filter only the detector rows the slab can read
     };
@@ -124,12 +125,19 @@ namespace paris
         paris_hip_ctx* ctx = nullptr;
         rt(paris_hip_ctx_create(device, nullptr, PARIS_HIP_CTX_DEFAULT, &ctx), "set_device()"); // :87
 
-        const int slots = po.slots < 1 ? 1 : po.slots;
+        // Projections travel in groups: a group of `batch` frames is converted, uploaded, weighted and filtered one by one,
+        // then backprojected with ONE fused launch (paris_hip_backproject_batch: bit-identical to the sequence, the slab is
+        // read and written once per group). While the GPU works on one group the host fills the next. batch = 1 (and the
+        // half-precision path) is the reference's one launch per projection with `slots` single-frame groups.
+        const std::uint32_t batch = po.f16 || po.batch < 1 ? 1u : static_cast<std::uint32_t>(po.batch > 32 ? 32 : po.batch);
+        const std::uint32_t groups = batch == 1u ? static_cast<std::uint32_t>(po.slots < 1 ? 1 : po.slots) : 2u;
+        const int slots = static_cast<int>(batch * groups);
         const auto n_row = po.det_geo.n_row, n_col = po.det_geo.n_col;
         const auto frame_bytes = static_cast<std::size_t>(n_row) * n_col * sizeof(float);
         auto h_buf = std::vector<float*>(slots, nullptr);
         auto d_buf = std::vector<float*>(slots, nullptr);
-        auto fence = std::vector<paris_hip_fence*>(slots, nullptr);
+        auto fence = std::vector<paris_hip_fence*>(groups, nullptr);
+        float* d_all = nullptr; // the device frames of all slots, one under the other: slot s starts at row s * n_col
         std::size_t d_pitch = 0, h16_pitch = 0;
         std::uint16_t* d_half = nullptr;
         float* d_v = nullptr;
@@ -137,12 +145,11 @@ namespace paris
         paris_hip_fence* stage_fence[2] = {nullptr, nullptr};
         std::size_t stage_floats = 0;
         auto cleanup = [&] {
+            for(auto f : fence)
+                paris_hip_fence_destroy(ctx, f);
             for(int s = 0; s < slots; ++s)
-            {
-                paris_hip_fence_destroy(ctx, fence[s]);
-                paris_hip_free(ctx, d_buf[s]);
                 paris_hip_free_host(ctx, h_buf[s]);
-            }
+            paris_hip_free(ctx, d_all);
             paris_hip_free(ctx, d_half);
             paris_hip_free(ctx, d_v);
             for(int s = 0; s < 2; ++s)
@@ -154,14 +161,19 @@ namespace paris
         };
         try
         {
+            if(static_cast<std::uint64_t>(n_col) * static_cast<std::uint64_t>(slots) > 0xffffffffull)
+                throw stage_construction_error{"too many projection slots for this detector"};
+            rt(paris_hip_malloc_projection(ctx, n_row, n_col * static_cast<std::uint32_t>(slots), &d_all, &d_pitch), "make_projection_device()");
+            const auto d_stride = d_pitch * n_col; // bytes from one slot's frame to the next
             for(int s = 0; s < slots; ++s)
             {
                 void* p = nullptr;
                 rt(paris_hip_malloc_host(ctx, frame_bytes, &p), "make_projection_host()");
                 h_buf[s] = static_cast<float*>(p);
-                rt(paris_hip_malloc_projection(ctx, n_row, n_col, &d_buf[s], &d_pitch), "make_projection_device()");
-                rt(paris_hip_fence_create(ctx, &fence[s]), "fence");
+                d_buf[s] = reinterpret_cast<float*>(reinterpret_cast<char*>(d_all) + d_stride * static_cast<std::size_t>(s));
             }
+            for(auto& f : fence)
+                rt(paris_hip_fence_create(ctx, &f), "fence");
             if(po.f16)
             {
                 float* raw = nullptr;
@@ -218,11 +230,27 @@ namespace paris
                 auto t0 = clock::now();
                 frame_stream src{t.input_path, t.enable_angles, t.angle_path, t.quality}; // :93 (index restarts per task)
                 rep.source_s += since(t0);
-                int slot = 0;
+                std::uint32_t group = 0, filled = 0; // frames of the current group already enqueued
+                auto sines = std::vector<float>(batch), cosines = std::vector<float>(batch);
+                const float delta_s = t.det_geo.delta_s * t.det_geo.l_px_row, delta_t = t.det_geo.delta_t * t.det_geo.l_px_col; // src/backprojection.cpp:49-50
+                const auto flush = [&] { // one fused launch for the frames of the current group, then on to the other group
+                    if(filled == 0)
+                        return;
+                    const auto t1 = clock::now();
+                    rt(paris_hip_backproject_batch(ctx, d_buf[group * batch], d_pitch, d_stride, filled, n_row, n_col, d_v, t.subvol_geo.dim_x,
+                                                   t.subvol_geo.dim_y, dim_z, offset, &t.det_geo, &t.vol_geo, t.enable_roi, &t.roi, sines.data(),
+                                                   cosines.data(), delta_s, delta_t), "backproject()"); // :104
+                    rt(paris_hip_fence_record(ctx, fence[group]), "fence record"); // the group's slots are free once this has run
+                    rep.enqueue_s += since(t1);
+                    group = (group + 1u) % groups;
+                    filled = 0;
+                };
                 for(;;) // :98
                 {
+                    const int slot = static_cast<int>(group * batch + filled);
                     t0 = clock::now();
-                    rt(paris_hip_fence_wait(ctx, fence[slot]), "fence wait"); // everything that last used this slot is done
+                    if(filled == 0)
+                        rt(paris_hip_fence_wait(ctx, fence[group]), "fence wait"); // everything that last used this group's slots is done
                     rep.enqueue_s += since(t0);
                     // f4: only the detector rows this slab can read are converted, uploaded, weighted and filtered; the
                     // buffers keep their full size, rows outside the band are never read for a voxel of the slab
@@ -236,35 +264,36 @@ namespace paris
                     t0 = clock::now();
                     const auto band_off = static_cast<std::size_t>(band_first) * n_row;
                     auto* d_band = reinterpret_cast<float*>(reinterpret_cast<char*>(d_buf[slot]) + static_cast<std::size_t>(band_first) * d_pitch);
-                    // :101 -- on the upload stream, overlapping the kernels of the previous projections
                     if(band_count != 0)
                     {
+                        // :101 -- on the upload stream, overlapping the kernels of the previous projections
                         rt(paris_hip_upload_projection(ctx, d_band, d_pitch, h_buf[slot] + band_off, row_bytes, n_row, band_count), "load()");
                         rt(paris_hip_stage_weight_rows(ctx, d_buf[slot], d_pitch, n_row, n_col, band_first, band_count, &t.det_geo), "weight()"); // :102
                         rt(paris_hip_stage_filter_rows(ctx, d_buf[slot], d_pitch, n_row, n_col, band_first, band_count, &t.det_geo), "filter()"); // :103
                     }
+                    rt(paris_hip_stage_angle(&t.det_geo, p.idx, t.enable_angles, p.phi, &sines[filled], &cosines[filled]), "angle"); // src/backprojection.cpp:52-63
                     if(po.f16)
                     {
                         if(band_count != 0)
                             rt(paris_hip_convert_projection_f16(ctx, d_band, d_pitch,
                                                                 reinterpret_cast<std::uint16_t*>(reinterpret_cast<char*>(d_half) + static_cast<std::size_t>(band_first) * h16_pitch),
                                                                 h16_pitch, n_row, band_count), "to half");
-                        const float delta_s = t.det_geo.delta_s * t.det_geo.l_px_row, delta_t = t.det_geo.delta_t * t.det_geo.l_px_col;
-                        float sn = 0.f, cs = 0.f;
-                        rt(paris_hip_stage_angle(&t.det_geo, p.idx, t.enable_angles, p.phi, &sn, &cs), "angle");
                         rt(paris_hip_backproject_f16(ctx, d_half, h16_pitch, n_row, n_col, d_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z,
-                                                     offset, &t.det_geo, &t.vol_geo, t.enable_roi, &t.roi, sn, cs, delta_s, delta_t),
+                                                     offset, &t.det_geo, &t.vol_geo, t.enable_roi, &t.roi, sines[0], cosines[0], delta_s, delta_t),
                            "backproject()");
+                        rt(paris_hip_fence_record(ctx, fence[group]), "fence record");
+                        group = (group + 1u) % groups;
+                        rep.enqueue_s += since(t0);
                     }
                     else
-                        rt(paris_hip_stage_backproject(ctx, d_buf[slot], d_pitch, n_row, n_col, p.idx, p.phi, d_v, t.subvol_geo.dim_x,
-                                                       t.subvol_geo.dim_y, dim_z, offset, &t.det_geo, &t.vol_geo, t.enable_angles,
-                                                       t.enable_roi, &t.roi), "backproject()"); // :104
-                    rt(paris_hip_fence_record(ctx, fence[slot]), "fence record"); // slot reusable once its backprojection is done
-                    rep.enqueue_s += since(t0);
-                    slot = (slot + 1) % slots;
+                    {
+                        rep.enqueue_s += since(t0);
+                        if(++filled == batch)
+                            flush();
+                    }
                     ++rep.projections;
                 }
+                flush(); // the last, possibly partial group
                 for(const auto& s : src.skipped_files())
                     rep.skipped.push_back(s);
 
