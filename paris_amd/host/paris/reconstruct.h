@@ -5,9 +5,10 @@
 // sink shared by all threads.
 // What is rebuilt for the GPU:
 //   - the per-projection chain is enqueued asynchronously on the device's stream; the host thread meanwhile reads and
-//     converts the next HIS frame into one of `slots` pinned upload buffers (each slot = pinned host + device buffer,
-//     guarded by a stream fence recorded after its backprojection); the upload runs on a second stream and the
-//     compute stream waits for it by event, so file I/O, PCIe upload and GPU work all overlap;
+//     converts the next HIS frame into a pinned upload slot (slot = pinned host + device frame); the upload runs on a
+//     second stream and the compute stream waits for it by event, so file I/O, PCIe upload and GPU work all overlap;
+//   - slots form two groups of `batch` frames; a full group is backprojected by one fused launch and guarded by a
+//     stream fence, the host fills the other group meanwhile;
 //   - per slab only the detector rows it can read are converted, uploaded, weighted and filtered (8f-4,
 //     paris_hip_slab_row_band); the slab reaches the file through two pinned chunks (D2H of one overlapping the write
 //     of the other) instead of a pinned copy of the whole slab;

@@ -234,3 +234,26 @@ def test_slab_row_band_covers_every_tap(seed):
     counts = [B.slab_row_band(det, vg, 2048, 2048, 256, 256 * g)[1] for g in range(8)]
     assert max(counts) < 0.4 * 2048 and counts == counts[::-1]
     assert B.slab_row_band(det, vg, 2048, 2048, 2048, 0) == (0, 2048)
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/paris_hip.h must compile as strict C99 and as C++11, and a C program
+    must link against the library by name."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "paris_hip.h"\n'
+                   'int main(void) { paris_detector_geometry g; paris_volume_geometry v; g.n_row = 64; g.n_col = 48;\n'
+                   '  g.l_px_row = 0.2f; g.l_px_col = 0.25f; g.delta_s = 1.5f; g.delta_t = -0.75f; g.d_so = 100.f; g.d_od = 200.f;\n'
+                   '  g.delta_phi = 45.f; if(paris_hip_calculate_volume_geometry(&g, &v)) return 2;\n'
+                   '  return (v.dim_x == 67 && v.dim_z == 61 && paris_hip_filter_size(64) == 128) ? 0 : 1; }\n')
+    inc = os.path.join(root, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o",
+                           str(tmp_path / "c.o")])
+    subprocess.check_call(["g++", "-std=c++11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-c", str(src),
+                           "-o", str(tmp_path / "cxx.o")])
+    lib_dir = os.path.join(root, "paris_amd", "lib")
+    exe = tmp_path / "hdr"
+    subprocess.check_call(["gcc", str(tmp_path / "c.o"), "-o", str(exe), "-L", lib_dir, "-lparis_hip", "-Wl,-rpath," + lib_dir,
+                           "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.run([str(exe)]).returncode == 0  # geometry entry points need no device

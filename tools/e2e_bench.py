@@ -31,6 +31,9 @@ for k in range(0, n_proj, per_file):
 print("wrote %d frames of %dx%d u16 in %.1f s" % (n_proj, n, n, time.time() - t0), flush=True)
 with open(os.path.join(work, "geo.ini"), "w") as f:
     f.write("n_row=%d\nn_col=%d\nl_px_row=0.2\nl_px_col=0.2\ndelta_s=0\ndelta_t=0\nd_so=500\nd_od=500\ndelta_phi=%r\n" % (n, n, 360.0 / n_proj))
+if os.environ.get("PARIS_E2E_WRITE_ONLY"):  # leave the data set in `work` for a profiler run of paris.hip itself
+    print("data set kept in", work)
+    sys.exit(0)
 t0 = time.time()
 r = subprocess.run([exe, "--geometry", os.path.join(work, "geo.ini"), "--input", os.path.join(work, "in"), "--output",
                     os.path.join(work, "out")] + sys.argv[5:], capture_output=True, text=True)
