@@ -48,7 +48,7 @@ namespace paris
         int devices = 0;   // 0: all
         int slots = 4;     // pinned upload buffers per device
         bool f16 = false;  // store filtered projections as IEEE half before backprojection (BASELINE config 5)
-        int batch = 8;     // projections per fused backprojection launch (1: one launch per projection, as the reference)
+        int batch = 16;    // projections per fused backprojection launch (1: one launch per projection, as the reference)
         std::size_t drain_chunk_bytes = std::size_t{256} << 20; // pinned staging per buffer for the volume's way to the file
         bool row_band = true; // f4: per slab, upload / weight / filter only the detector rows the slab can read
     };
