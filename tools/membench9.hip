@@ -52,7 +52,14 @@ __global__ void __launch_bounds__(256) tile_global(float* vol, uint32_t dx, uint
     const uint32_t l = by * 16 + wave * 4 + (lane >> 4);
     const size_t slice = (size_t)dx * dy;
     float* vp = vol + ((size_t)bz * TZ * dy + l) * dx + k;
-    for(uint32_t mm = 0; mm < TZ; mm += 2)
+    if(TZ == 1)
+    {
+        v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(vp));
+        a += 1.f;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(vp), "v"(a) : "memory");
+        return;
+    }
+    for(uint32_t mm = 0; mm + 1 < TZ; mm += 2)
     {
         v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(vp + mm * slice));
         v4f c = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(vp + (mm + 1) * slice));
@@ -75,6 +82,8 @@ int main()
     const unsigned grid = (dx / 64) * (dy / 16) * (dz / 16);
     std::vector<Variant> vs;
     vs.push_back({"global nt load / sc1 nt store (kernel today)", [=] { tile_global<16><<<grid, 256>>>(a, dx, dy, dz); }, {}});
+#define ADDTZ(TZ) vs.push_back({"global nt / sc1 nt, tile depth " #TZ, [=] { tile_global<TZ><<<(dx / 64) * (dy / 16) * (dz / TZ), 256>>>(a, dx, dy, dz); }, {}})
+    ADDTZ(1); ADDTZ(2); ADDTZ(4); ADDTZ(8); ADDTZ(32); ADDTZ(64);
 #define ADD(LD, ST) vs.push_back({"buffer load aux " #LD " store aux " #ST, [=] { tile<LD, ST, 16><<<grid, 256>>>(a, dx, dy, dz); }, {}})
     ADD(2, 18); ADD(0, 18); ADD(1, 18); ADD(3, 18); ADD(16, 18); ADD(17, 18); ADD(18, 18); ADD(19, 18);
     ADD(2, 2); ADD(2, 16); ADD(2, 19); ADD(2, 17); ADD(2, 3); ADD(2, 0); ADD(18, 19); ADD(19, 19); ADD(0, 0);
