@@ -69,6 +69,35 @@ __global__ void __launch_bounds__(256) tile_global(float* vol, uint32_t dx, uint
     }
 }
 
+// in-flight accesses of a lane within ONE slice: R rows (l, l + 16, ...) of a 64 x 16R x TZ tile per z step
+template <int R, int TZ>
+__global__ void __launch_bounds__(256) tile_rows(float* vol, uint32_t dx, uint32_t dy, uint32_t dz)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t ntx = dx / 64, nty = dy / (16 * R), ntz = dz / TZ;
+    const uint32_t per = (ntx * nty * ntz) / 8u;
+    uint32_t b = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
+    const uint32_t bx = b % ntx; b /= ntx;
+    const uint32_t by = b % nty; const uint32_t bz = b / nty;
+    const uint32_t k = bx * 64 + (lane & 15u) * 4u;
+    const uint32_t l = by * 16 * R + wave * 4 + (lane >> 4);
+    const size_t slice = (size_t)dx * dy;
+    float* vp = vol + ((size_t)bz * TZ * dy + l) * dx + k;
+    for(uint32_t mm = 0; mm < TZ; ++mm)
+    {
+        v4f a[R];
+#pragma unroll
+        for(int r = 0; r < R; ++r)
+            a[r] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(vp + mm * slice + (size_t)r * 16 * dx));
+#pragma unroll
+        for(int r = 0; r < R; ++r)
+        {
+            a[r] += 1.f;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(vp + mm * slice + (size_t)r * 16 * dx), "v"(a[r]) : "memory");
+        }
+    }
+}
+
 hipEvent_t ea, eb;
 struct Variant { std::string name; std::function<void()> f; std::vector<float> ms; };
 
@@ -84,6 +113,8 @@ int main()
     vs.push_back({"global nt load / sc1 nt store (kernel today)", [=] { tile_global<16><<<grid, 256>>>(a, dx, dy, dz); }, {}});
 #define ADDTZ(TZ) vs.push_back({"global nt / sc1 nt, tile depth " #TZ, [=] { tile_global<TZ><<<(dx / 64) * (dy / 16) * (dz / TZ), 256>>>(a, dx, dy, dz); }, {}})
     ADDTZ(1); ADDTZ(2); ADDTZ(4); ADDTZ(8); ADDTZ(32); ADDTZ(64);
+#define ADDR(R, TZ) vs.push_back({"rows in flight " #R ", tile depth " #TZ, [=] { tile_rows<R, TZ><<<(dx / 64) * (dy / (16 * R)) * (dz / TZ), 256>>>(a, dx, dy, dz); }, {}})
+    ADDR(1, 16); ADDR(2, 16); ADDR(4, 16); ADDR(2, 8); ADDR(4, 8); ADDR(2, 32); ADDR(4, 4); ADDR(8, 4); ADDR(2, 1); ADDR(4, 1);
 #define ADD(LD, ST) vs.push_back({"buffer load aux " #LD " store aux " #ST, [=] { tile<LD, ST, 16><<<grid, 256>>>(a, dx, dy, dz); }, {}})
     ADD(2, 18); ADD(0, 18); ADD(1, 18); ADD(3, 18); ADD(16, 18); ADD(17, 18); ADD(18, 18); ADD(19, 18);
     ADD(2, 2); ADD(2, 16); ADD(2, 19); ADD(2, 17); ADD(2, 3); ADD(2, 0); ADD(18, 19); ADD(19, 19); ADD(0, 0);
