@@ -85,6 +85,9 @@ typedef struct paris_hip_ctx paris_hip_ctx;
 
 /* ---- device management: backend::get_devices / set_device (src/cuda/device.cpp:31-47,
  *      src/openmp/backend.h:87-89) -------------------------------------------------------------------- */
+/* Environment switches (diagnostics, read once per process): PARIS_HIP_VIRTUAL_DEVICES=k reports k device handles
+ * mapped round-robin onto the physical GPUs (exercises the one-thread-per-device driver on a one-GPU box);
+ * PARIS_HIP_UPLOAD_STREAM=0 keeps paris_hip_upload_projection on the compute stream (A/B of the overlap). */
 int paris_hip_device_count(int* count);
 
 /* Creates the per-device state. `stream` is a hipStream_t to enqueue on (e.g. the caller's torch stream),

@@ -11,19 +11,39 @@
 #include <cstring>
 #include <new>
 
+namespace
+{
+    int physical_device_count(int* count)
+    {
+        int n = 0;
+        const hipError_t err = hipGetDeviceCount(&n);
+        if(err == hipErrorNoDevice)
+        {
+            *count = 0;
+            return PARIS_HIP_SUCCESS;
+        }
+        PARIS_HIP_TRY(err);
+        *count = n;
+        return PARIS_HIP_SUCCESS;
+    }
+
+    // Test hook: PARIS_HIP_VIRTUAL_DEVICES=k reports k device handles that map round-robin onto the physical GPUs, so the
+    // one-host-thread-per-device driver (several ctxs, a shared task queue and sink) can be exercised on a one-GPU box.
+    int virtual_devices()
+    {
+        static const int k = [] { const char* e = std::getenv("PARIS_HIP_VIRTUAL_DEVICES"); return e ? std::atoi(e) : 0; }();
+        return k;
+    }
+}
+
 extern "C" int paris_hip_device_count(int* count)
 {
     if(count == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    int n = 0;
-    const hipError_t err = hipGetDeviceCount(&n);
-    if(err == hipErrorNoDevice)
-    {
-        *count = 0;
-        return PARIS_HIP_SUCCESS;
-    }
-    PARIS_HIP_TRY(err);
-    *count = n;
+    if(int rc = physical_device_count(count))
+        return rc;
+    if(*count > 0 && virtual_devices() > *count)
+        *count = virtual_devices();
     return PARIS_HIP_SUCCESS;
 }
 
@@ -39,6 +59,10 @@ extern "C" int paris_hip_ctx_create(int device, void* stream, unsigned flags, pa
         return PARIS_HIP_ERROR_NO_DEVICE;
     if(device < 0 || device >= n)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    int physical = 0;
+    if(int rc = physical_device_count(&physical))
+        return rc;
+    device %= physical; // identity unless PARIS_HIP_VIRTUAL_DEVICES is set
     PARIS_HIP_TRY(hipSetDevice(device)); // set_device: src/cuda/device.cpp:40-47
 
     paris_hip_ctx* ctx = new(std::nothrow) paris_hip_ctx;
@@ -406,9 +430,12 @@ extern "C" int paris_hip_make_subvolume_information(const paris_volume_geometry*
 
     int current = 0;
     (void)hipGetDevice(&current);
+    int physical = 0;
+    if(int rc = physical_device_count(&physical))
+        return rc;
     for(int d = 0; d < devices; ++d)
     {
-        PARIS_HIP_TRY(hipSetDevice(d));
+        PARIS_HIP_TRY(hipSetDevice(d % physical));
         size_t mem_free = 0, mem_total = 0;
         PARIS_HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
         mem_free -= mem_free / 20u;

@@ -88,6 +88,27 @@ def test_chunked_drain_and_row_band_switch(tmp_path, oracle, extra):
         assert_close(vol, want)
 
 
+def test_one_thread_per_device_fan_out(tmp_path, oracle):
+    """src/main.cpp:157-167: one host thread per device, all draining one task queue and writing through one sink.
+    PARIS_HIP_VIRTUAL_DEVICES=3 gives the one GPU of the test box three device handles (three threads, three ctxs)."""
+    geo = write_dataset(oracle, tmp_path / "in")
+    env = dict(os.environ, PARIS_HIP_VIRTUAL_DEVICES="3")
+    r = subprocess.run([EXE, "--geometry", geo, "--input", str(tmp_path / "in"), "--output", str(tmp_path / "out"), "--name", "kat",
+                        "--slabs", "7"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("device ")]
+    assert len(lines) == 3 and sum(int(l.split(":")[1].split()[0]) for l in lines) == 7  # 7 tasks over 3 threads
+    head, vol = F.ddbvf_read(str(tmp_path / "out" / "kat.ddbvf"))
+    assert head == F.ddbvf_header_bytes(67, 67, 61)
+    assert_close(vol, oracle_volume(oracle, range(8)))
+    # the memory-driven split sees three devices: at least one slab per device (src/cuda/subvolume_information.cpp:79)
+    r = subprocess.run([EXE, "--geometry", geo, "--input", str(tmp_path / "in"), "--output", str(tmp_path / "out2")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "(3 slabs)" in r.stdout, r.stdout + r.stderr
+    _, vol = F.ddbvf_read(str(tmp_path / "out2" / "vol.ddbvf"))
+    assert_close(vol, oracle_volume(oracle, range(8)))
+
+
 def test_roi_quality_and_angles(tmp_path, oracle):
     geo = write_dataset(oracle, tmp_path / "in", files=(8,))
     ang = tmp_path / "angles.txt"
