@@ -16,7 +16,7 @@ _u32p = C.POINTER(C.c_uint32)
 
 @pytest.fixture(scope="module")
 def io():
-    lib = C.CDLL(os.path.join(ROOT, "paris_amd", "lib", "libparis_io.so"))
+    lib = C.CDLL(os.environ.get("PARIS_IO_LIB") or os.path.join(ROOT, "paris_amd", "lib", "libparis_io.so"))  # `make sanitize`
     lib.paris_io_his_load.argtypes = [C.c_char_p, _u32p, _u32p, _u32p, C.POINTER(_fp)]
     lib.paris_io_free.argtypes = [C.c_void_p]
     lib.paris_io_his_save.argtypes = [C.c_char_p, _fp, C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint16]
