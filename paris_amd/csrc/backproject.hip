@@ -450,12 +450,21 @@ namespace
         else
             valid = (y1 >= 0.f) && (y2 < col.ymax); // :67-68 (+ x validity)
         const int rc = min(max(rrel, 0), max(bhs_m2, 0));
-        // rc < 2^12 and stride < 2^14: the 24-bit multiply-add is one full-rate instruction (v_mul_lo_u32 is quarter rate)
-        const int base = __mul24(rc, b.stride) + max(col.xoff, 0);
-        float q11 = lds_box[base];
-        float q21 = lds_box[base + 1];
-        float q12 = lds_box[base + b.stride];
-        float q22 = lds_box[base + b.stride + 1];
+        // LDS byte address of the upper left tap = row * stride4 + (box base + 4 * column): the second term is z-invariant
+        // (hoisted with the column state), so a tap pair costs one 24-bit multiply-add (rc < 2^12, stride4 < 2^16;
+        // v_mul_lo_u32 is quarter rate) and the row below one add. Integer addresses keep the compiler from adding the
+        // (zero) link-time base of the dynamic LDS array to every access.
+        using lds_cptr = const __attribute__((address_space(3))) float*;
+        const int stride4 = b.stride << 2;
+        const uint32_t xaddr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_box)) + (static_cast<uint32_t>(max(col.xoff, 0)) << 2);
+        const uint32_t a1 = static_cast<uint32_t>(__mul24(rc, stride4)) + xaddr;
+        const uint32_t a2 = a1 + static_cast<uint32_t>(stride4);
+        lds_cptr r1 = reinterpret_cast<lds_cptr>(a1);
+        lds_cptr r2 = reinterpret_cast<lds_cptr>(a2);
+        float q11 = r1[0];
+        float q21 = r1[1];
+        float q12 = r2[0];
+        float q22 = r2[1];
         if(!FAST)
         {
             const bool inbox = col.xoff >= 0 && rrel >= 0 && rrel <= bhs_m2;
