@@ -449,7 +449,9 @@ namespace
         }
         else
             valid = (y1 >= 0.f) && (y2 < col.ymax); // :67-68 (+ x validity)
-        const int rc = min(max(rrel, 0), max(bhs_m2, 0));
+        // clamp of the row to the staged box: one median instruction (the compiler's min/max pair cannot know 0 <= hi)
+        int rc;
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(rc) : "v"(rrel), "v"(max(bhs_m2, 0)));
         // LDS byte address of the upper left tap = row * stride4 + (box base + 4 * column): the second term is z-invariant
         // (hoisted with the column state), so a tap pair costs one 24-bit multiply-add (rc < 2^12, stride4 < 2^16;
         // v_mul_lo_u32 is quarter rate) and the row below one add. Integer addresses keep the compiler from adding the
