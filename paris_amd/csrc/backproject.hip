@@ -483,8 +483,13 @@ namespace
         }
         const float interp_y1 = col.wx2 * q11 + col.wx1 * q21; // :77
         const float interp_y2 = col.wx2 * q12 + col.wx1 * q22; // :78
-        // :80 divides by (y2 - y1) == 1.f exactly whenever valid -- dropped, as above
-        float det = (y2 - v) * interp_y1 + (v - y1) * interp_y2;
+        // :80 divides by (y2 - y1) == 1.f exactly whenever valid -- dropped, as above.
+        // For a valid tap (v >= 0) both v - y1 and y2 - v are exact: below 1 they are v and RN(1 - v), from 1 up multiples
+        // of ulp(v) >= 2^-23 inside [0, 1]. So y2 - v == 1 - (v - y1) bit for bit, and the fast path (which does not need y2
+        // for its validity test) saves the addition; for an invalid tap the value is discarded below.
+        const float wy1 = v - y1;
+        const float wy2 = FAST ? 1.f - wy1 : y2 - v;
+        float det = wy2 * interp_y1 + wy1 * interp_y2;
         det = valid ? det : 0.f;         // :71
         return 0.5f * det * col.u * col.u; // :140
     }
