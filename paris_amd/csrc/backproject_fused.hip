@@ -1,0 +1,138 @@
+// Fused multi-projection backprojection kernel (paris_hip_backproject_batch) for gfx950.
+//
+// A translation unit of its own: its hot loop is bound by LDS / ALU latency at three waves per SIMD, and clang's SLP
+// vectoriser turns its fp32 multiplies and adds into v_pk_mul_f32 / v_pk_add_f32, which on gfx950 issue at half the
+// rate of the plain instructions (tools/pkbench.hip) and need v_mov packing on top: -fno-slp-vectorize (Makefile) is
+// worth +12 % here, while the memory-bound tile kernel in backproject.hip is indifferent to it.
+#include "bp_device.h"
+
+namespace
+{
+    // (Double-buffering the box with the next projection's loads kept in flight was measured slower: the kernel is
+    // bound by vector ALU issue, not by staging latency, and the extra live registers cost occupancy.)
+    // Waves per SIMD the fused kernel is compiled for: its loop is bound by LDS/ALU latency, not by issue slots, so a
+    // third resident wave (<= 168 VGPRs, a few cold-path spills) is worth +10 % over the compiler's unconstrained 196.
+#ifndef PARIS_FUSED_WAVES
+#define PARIS_FUSED_WAVES 3
+#endif
+    template <int TZ, bool NT, bool FD>
+    __global__ void __launch_bounds__(256, PARIS_FUSED_WAVES) bp_fused_kernel(const FusedParams fp)
+    {
+        extern __shared__ __attribute__((aligned(16))) float lds[];
+        BpParams g = fp.g;
+
+        const uint32_t tid = threadIdx.x;
+        const uint32_t lane = tid & 63u;
+        const uint32_t wave = tid >> 6;
+
+        uint32_t bx, by, bz;
+        if(!tile_of_block(g, blockIdx.x, bx, by, bz))
+            return;
+        const uint32_t k0 = bx * 64u;
+        const uint32_t l0 = by * 16u;
+        const uint32_t m0 = bz * TZ;
+        const uint32_t k1 = min(k0 + 63u, g.v_dim_x - 1u);
+        const uint32_t l1 = min(l0 + 15u, g.v_dim_y - 1u);
+        const uint32_t m1 = min(m0 + TZ - 1u, g.v_dim_z - 1u);
+        const uint32_t mcount = m1 - m0 + 1u;
+
+        const uint32_t xq = lane & 15u, yy = lane >> 4;
+        const uint32_t k = k0 + xq * 4u;
+        const uint32_t l = l0 + wave * 4u + yy;
+        const bool active = k < g.v_dim_x && l < g.v_dim_y; // inactive lanes still take part in the barriers
+
+        const size_t slice = static_cast<size_t>(g.v_dim_x) * g.v_dim_y;
+        float* vp = g.vol + (static_cast<size_t>(m0) * g.v_dim_y + l) * g.v_dim_x + k;
+        float4 acc[TZ];
+#pragma unroll
+        for(int z = 0; z < TZ; ++z)
+            if(active && static_cast<uint32_t>(z) < mcount)
+                acc[z] = load_voxels<4, NT>(vp + z * slice);
+
+        const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
+        const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
+        const char* base = static_cast<const char*>(fp.g.proj);
+        const size_t px = g.proj_f16 ? 2u : 4u;
+        for(uint32_t p = 0; p < fp.n_proj; ++p)
+        {
+            g.sin_phi = fp.sin_phi[p];
+            g.cos_phi = fp.cos_phi[p];
+            g.proj = base + static_cast<size_t>(p) * fp.proj_stride * px;
+            const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats);
+            __syncthreads(); // the previous projection's taps are done with the LDS box
+            stage_box(g, box, lds, wave, 4u, lane);
+            __syncthreads();
+            if(active)
+            {
+                Column col[4];
+                bool all_fast = true;
+#pragma unroll
+                for(int j = 0; j < 4; ++j)
+                {
+                    col[j] = make_column<FD>(g, box, g.k_off + k + j, g.l_off + l, z_first, z_last);
+                    all_fast = all_fast && col[j].fast;
+                }
+                auto add_projection = [&](auto fast_tag, auto full_tag) {
+                    constexpr bool FAST = decltype(fast_tag)::value;
+                    constexpr bool FULL = decltype(full_tag)::value; // whole tile: no per-slice test, one straight block
+#pragma unroll
+                    for(int z = 0; z < TZ; ++z)
+                    {
+                        if(FULL || static_cast<uint32_t>(z) < mcount) // uniform; no break, so acc stays in registers
+                        {
+                            const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + z) * g.l_vx_z; // :118
+                            acc[z].x += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[0]);
+                            acc[z].y += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[1]);
+                            acc[z].z += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[2]);
+                            acc[z].w += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[3]);
+                        }
+                    }
+                };
+                if(all_fast && mcount == TZ)
+                    add_projection(std::true_type{}, std::true_type{});
+                else if(all_fast)
+                    add_projection(std::true_type{}, std::false_type{});
+                else
+                    add_projection(std::false_type{}, std::false_type{});
+            }
+        }
+#pragma unroll
+        for(int z = 0; z < TZ; ++z)
+            if(active && static_cast<uint32_t>(z) < mcount)
+                store_voxels<4, NT>(vp + z * slice, acc[z]);
+    }
+
+    template <int TZ, bool NT, bool FD>
+    void launch_fused(FusedParams& fp, hipStream_t stream)
+    {
+        BpParams& g = fp.g;
+        g.tz = TZ;
+        g.ntx = (g.v_dim_x + 63u) / 64u;
+        g.nty = (g.v_dim_y + 15u) / 16u;
+        g.ntz = (g.v_dim_z + TZ - 1u) / TZ;
+        uint32_t blocks = grid_blocks(g);
+        hipLaunchKernelGGL((bp_fused_kernel<TZ, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, fp);
+    }
+
+    template <int TZ>
+    void launch_fused_flags(FusedParams& fp, bool nt, bool fd, hipStream_t stream)
+    {
+        if(nt && fd)
+            launch_fused<TZ, true, true>(fp, stream);
+        else if(nt)
+            launch_fused<TZ, true, false>(fp, stream);
+        else if(fd)
+            launch_fused<TZ, false, true>(fp, stream);
+        else
+            launch_fused<TZ, false, false>(fp, stream);
+    }
+}
+
+void paris_hip_bp_launch_fused(const void* fused_params, int tz, bool nt, bool fd, hipStream_t stream)
+{
+    FusedParams fp = *static_cast<const FusedParams*>(fused_params);
+    if(tz == 8)
+        launch_fused_flags<8>(fp, nt, fd, stream);
+    else
+        launch_fused_flags<16>(fp, nt, fd, stream);
+}

@@ -1,0 +1,483 @@
+// Device-side building blocks shared by the backprojection kernels (backproject.hip: tile / slice / gather kernels and
+// the host entry points; backproject_fused.hip: the fused multi-projection kernel, a translation unit of its own because
+// it is compiled with -fno-slp-vectorize, see the Makefile). Everything here has internal linkage.
+#ifndef PARIS_HIP_BP_DEVICE_H_
+#define PARIS_HIP_BP_DEVICE_H_
+
+#include "paris_hip_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <type_traits>
+
+namespace
+{
+    struct BpParams
+    {
+        const void* proj;     // fp32 pixels, or IEEE half pixels when proj_f16 != 0
+        uint32_t proj_f16;
+        float* vol;
+        uint32_t p_pitch; // pixels per detector row
+        uint32_t p_dim_x, p_dim_y;
+        uint32_t v_dim_x, v_dim_y, v_dim_z;
+        uint32_t k_off, l_off, m_off; // roi.x1, roi.y1, roi.z1 + v_offset
+        float x_base, y_base, z_base; // -(dim_full * l_vx/2) + l_vx/2
+        float l_vx_x, l_vx_y, l_vx_z;
+        float sin_phi, cos_phi;
+        float d_so, d_sd;
+        float min_h, min_v; // -(p_dim * l_px/2) - delta
+        float l_px_x, l_px_y;
+        float rcp_l_px_y; // RN(1 / l_px_y), used only by the validated fast division
+        float rcp_l_px_x;
+        float p_dim_x_f, p_dim_y_f;
+        uint32_t lds_floats;
+        uint32_t tz; // slices per tile
+        uint32_t ntx, nty, ntz; // tiles per axis
+        uint32_t order;         // workgroup -> tile mapping, see tile_of_block
+        uint32_t store_sc1;     // nontemporal stores also carry sc1 (write-through)
+        uint32_t stage_vec4;    // detector rows may be staged 4 pixels at a time (base and pitch aligned)
+    };
+
+    struct ColConst
+    {
+        float factor, h, u;
+    };
+
+    // x / c for a divisor c that is constant over the launch, with r = RN(1 / c): one multiply and two FMAs
+    // (Markstein's correction step) instead of the ~10-instruction IEEE sequence. Only used after
+    // fastdiv_validate_kernel has checked, for THIS c and EVERY fp32 x, that the result has the bits of x / c.
+    __device__ __forceinline__ float div_by_constant(float x, float c, float r)
+    {
+        const float q = x * r;
+        const float e = __builtin_fmaf(-q, c, x); // exact remainder
+        return __builtin_fmaf(e, r, q);
+    }
+
+    // src/openmp/backprojection.cpp:116-129,139 for one (x,y) column; K, L are global voxel indices. FD: the division
+    // by the horizontal pixel pitch uses the validated multiply + 2 FMA form (h = q - 0.5 has the shape the exhaustive
+    // check covers; an h beyond +-2^24 makes the column invalid either way).
+    template <bool FD>
+    __device__ __forceinline__ ColConst column_constants(const BpParams& g, uint32_t K, uint32_t L)
+    {
+        const float x_k = g.x_base + static_cast<float>(K) * g.l_vx_x; // :39-43
+        const float y_l = g.y_base + static_cast<float>(L) * g.l_vx_y;
+        const float s = x_k * g.cos_phi + y_l * g.sin_phi;  // :121
+        const float t = -x_k * g.sin_phi + y_l * g.cos_phi; // :122
+        const float den = s + g.d_so;
+        ColConst c;
+        c.factor = g.d_sd / den; // :125
+        const float b = (t * c.factor) - g.min_h;
+        const float q = FD ? div_by_constant(b, g.l_px_x, g.rcp_l_px_x) : b / g.l_px_x;
+        c.h = q - (1.f / 2.f);     // :45-50
+        c.u = -(g.d_so / den);     // :139
+        return c;
+    }
+
+    // v detector coordinate of slice z_m for a column with magnification `factor` (:130-133, :45-50)
+    template <bool FD>
+    __device__ __forceinline__ float v_coordinate(const BpParams& g, float z_m, float factor)
+    {
+        const float b = (z_m * factor) - g.min_v;
+        const float q = FD ? div_by_constant(b, g.l_px_y, g.rcp_l_px_y) : b / g.l_px_y;
+        return q - (1.f / 2.f);
+    }
+
+    __device__ __forceinline__ int to_int_clamped(float x)
+    {
+        x = fminf(fmaxf(x, -1.0e9f), 1.0e9f); // NaN -> -1e9
+        return static_cast<int>(floorf(x));
+    }
+
+    template <int VX> struct vec_of;
+    template <> struct vec_of<1> { using type = float; };
+    template <> struct vec_of<2> { using type = float2; };
+    template <> struct vec_of<4> { using type = float4; };
+
+    template <int VX> __device__ __forceinline__ float& elem(typename vec_of<VX>::type& v, int j);
+    template <> __device__ __forceinline__ float& elem<1>(float& v, int) { return v; }
+    template <> __device__ __forceinline__ float& elem<2>(float2& v, int j) { return j == 0 ? v.x : v.y; }
+    template <> __device__ __forceinline__ float& elem<4>(float4& v, int j)
+    {
+        return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+    }
+
+    // 1-D grid size for the tile mapping in g.order (tile_of_block rejects the padding blocks)
+    inline uint32_t grid_blocks(const BpParams& g)
+    {
+        const uint32_t total = g.ntx * g.nty * g.ntz;
+        if(g.order == 5u)
+            return ((total + 7u) / 8u) * 8u;
+        if(g.order == 8u)
+            return 8u * ((g.nty + 7u) / 8u) * g.ntx * g.ntz;
+        return total;
+    }
+
+    // ext-vector twins of float/float2/float4 for the nontemporal builtins
+    template <int VX> struct ext_of;
+    template <> struct ext_of<1> { typedef float type; };
+    template <> struct ext_of<2> { typedef float type __attribute__((ext_vector_type(2))); };
+    template <> struct ext_of<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+    // Volume voxels are touched exactly once per launch: with NT the loads/stores carry the nontemporal hint so
+    // the stream does not displace the projection from L2 / Infinity Cache (measured +5..10 % on z-walks).
+    template <int VX, bool NT> __device__ __forceinline__ typename vec_of<VX>::type load_voxels(const float* p)
+    {
+        using ext_t = typename ext_of<VX>::type;
+        using vec_t = typename vec_of<VX>::type;
+        ext_t e = NT ? __builtin_nontemporal_load(reinterpret_cast<const ext_t*>(p)) : *reinterpret_cast<const ext_t*>(p);
+        return *reinterpret_cast<vec_t*>(&e);
+    }
+    template <int VX, bool NT> __device__ __forceinline__ void store_voxels(float* p, typename vec_of<VX>::type v, bool sc1 = true)
+    {
+        using ext_t = typename ext_of<VX>::type;
+        const ext_t e = *reinterpret_cast<ext_t*>(&v);
+        if(NT && VX == 4 && sc1)
+        {
+            // Write-through + nontemporal ("sc1 nt") is the fastest policy for this once-written stream
+            // (tools/membench7.hip: +3 % over "nt" alone). No builtin emits that pair for a plain global store, so the
+            // store is inline asm; hipcc neither counts it (nothing waits on a store) nor pads it: the trailing
+            // s_nop 1 keeps the next instruction from overwriting the four data registers before they are read.
+            asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(e) : "memory");
+        }
+        else if(NT)
+            __builtin_nontemporal_store(e, reinterpret_cast<ext_t*>(p));
+        else
+            *reinterpret_cast<ext_t*>(p) = e;
+    }
+
+    // Workgroup -> tile mapping. Blocks are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8), and
+    // which tiles run concurrently decides the DRAM locality of the volume stream (tools/membench5.hip):
+    //   0: x tiles fastest, then y, then z (XCD k keeps hitting the same x columns: slowest)
+    //   1: z tiles fastest, then x, then y
+    //   5: XCD k sweeps its own contiguous eighth of the (x, y, z) tile sequence
+    //   8: XCD k owns a band of y tiles; x fastest, then z, then y inside the band (fastest: tools/membench5.hip)
+    __device__ __forceinline__ bool tile_of_block(const BpParams& g, uint32_t b, uint32_t& bx, uint32_t& by, uint32_t& bz)
+    {
+        const uint32_t total = g.ntx * g.nty * g.ntz;
+        if(g.order == 1u)
+        {
+            if(b >= total)
+                return false;
+            bz = b % g.ntz;
+            b /= g.ntz;
+            bx = b % g.ntx;
+            by = b / g.ntx;
+            return true;
+        }
+        if(g.order == 8u)
+        {
+            // XCD k owns the contiguous band k of y tiles for the whole slab; inside the band x runs fastest, then the
+            // z tile, then y: the tiles in flight on one XCD share their detector rows and sit in few DRAM pages
+            const uint32_t band = (g.nty + 7u) / 8u;
+            const uint32_t xcd = b % 8u;
+            uint32_t r = b / 8u;
+            bx = r % g.ntx;
+            r /= g.ntx;
+            bz = r % g.ntz;
+            const uint32_t yb = r / g.ntz;
+            by = xcd * band + yb;
+            return yb < band && by < g.nty;
+        }
+        if(g.order == 5u)
+        {
+            const uint32_t per = (total + 7u) / 8u;
+            b = (b % 8u) * per + b / 8u;
+        }
+        if(b >= total)
+            return false;
+        bx = b % g.ntx;
+        b /= g.ntx;
+        by = b % g.nty;
+        bz = b / g.nty;
+        return true;
+    }
+
+    // --------------------------------------------------------------------------------------------
+    // Pieces shared by the two LDS-staged kernels
+    // --------------------------------------------------------------------------------------------
+
+    // the staged detector box of one tile (workgroup-uniform)
+    struct Box
+    {
+        int bx0, by0; // first staged detector column / row
+        int bw;       // staged columns (0: nothing staged)
+        int bhs;      // staged rows
+        int stride;   // LDS row stride in floats (odd)
+    };
+
+    // Detector bounding box of the voxel tile [k0,k1] x [l0,l1] x [m0,m1]. h is a projective function of (x,y) and
+    // v of (z, factor), so the extremes sit on tile corners; the four corners are evaluated by four lanes in
+    // parallel and min/max-reduced with two butterfly shuffles (every wave computes the same box). The box is
+    // widened by the taps' reach plus one pixel of rounding slack, clipped to the detector and cut to the LDS
+    // budget; a tap that still falls outside is served from global memory, so this only has to be right for speed.
+    __device__ __forceinline__ Box tile_box(const BpParams& g, uint32_t k0, uint32_t k1, uint32_t l0, uint32_t l1,
+                                            uint32_t m0, uint32_t m1, uint32_t lane, uint32_t box_floats)
+    {
+        const uint32_t ci = lane & 3u;
+        const ColConst c = column_constants<false>(g, g.k_off + ((ci & 1u) ? k1 : k0), g.l_off + ((ci & 2u) ? l1 : l0));
+        float hmin = c.h, hmax = c.h, fmin = c.factor, fmax = c.factor;
+#pragma unroll
+        for(int m = 1; m <= 2; m <<= 1)
+        {
+            hmin = fminf(hmin, __shfl_xor(hmin, m));
+            hmax = fmaxf(hmax, __shfl_xor(hmax, m));
+            fmin = fminf(fmin, __shfl_xor(fmin, m));
+            fmax = fmaxf(fmax, __shfl_xor(fmax, m));
+        }
+        const float z_c = g.z_base + static_cast<float>(g.m_off + ((ci & 1u) ? m1 : m0)) * g.l_vx_z;
+        const float v_c = v_coordinate<false>(g, z_c, (ci & 2u) ? fmax : fmin);
+        float vmin = v_c, vmax = v_c;
+#pragma unroll
+        for(int m = 1; m <= 2; m <<= 1)
+        {
+            vmin = fminf(vmin, __shfl_xor(vmin, m));
+            vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+        }
+        // identical in every lane by construction; readfirstlane moves them to scalar registers
+        const int ihmin = __builtin_amdgcn_readfirstlane(to_int_clamped(hmin));
+        const int ihmax = __builtin_amdgcn_readfirstlane(to_int_clamped(hmax));
+        const int ivmin = __builtin_amdgcn_readfirstlane(to_int_clamped(vmin));
+        const int ivmax = __builtin_amdgcn_readfirstlane(to_int_clamped(vmax));
+
+        Box b;
+        b.bx0 = max(ihmin - 1, 0);
+        b.by0 = max(ivmin - 1, 0);
+        const int bx1 = min(ihmax + 2, static_cast<int>(g.p_dim_x) - 1);
+        const int by1 = min(ivmax + 2, static_cast<int>(g.p_dim_y) - 1);
+        b.bw = bx1 - b.bx0 + 1;
+        int bh = by1 - b.by0 + 1;
+        if(b.bw < 2 || bh < 2)
+        {
+            b.bw = 0;
+            bh = 0;
+        }
+        if(g.stage_vec4 && b.bw > 0)
+        {
+            // 4-pixel staging: start on a multiple of 4 and cover whole groups of 4. Columns past p_dim_x (< pitch,
+            // which is a multiple of 4 here) are readable padding that no valid tap addresses.
+            const int end = min((bx1 + 4) & ~3, static_cast<int>(g.p_pitch));
+            b.bx0 &= ~3;
+            b.bw = end - b.bx0;
+            b.stride = b.bw + 4; // multiple of 4: 16-byte aligned rows for ds_write_b128, not a power of two
+        }
+        else
+            b.stride = b.bw | 1;
+        b.bhs = min(bh, static_cast<int>(box_floats) / b.stride); // rows that fit the LDS budget
+        if(b.bhs < 2)
+        {
+            // nothing useful fits: stage nothing, every valid tap takes the global path
+            b.bw = 0;
+            b.bhs = 0;
+            b.stride = 1;
+        }
+        return b;
+    }
+
+    // one detector pixel from global memory as fp32 (half pixels widen exactly); idx in pixels
+    __device__ __forceinline__ float read_pixel(const BpParams& g, size_t idx)
+    {
+        if(g.proj_f16)
+            return static_cast<float>(static_cast<const volatile _Float16*>(g.proj)[idx]);
+        return static_cast<const volatile float*>(g.proj)[idx];
+    }
+
+    // global -> LDS. Aligned projections (stage_vec4) move 4 pixels per lane and instruction (16 B fp32 / 8 B half),
+    // several short rows per wave-instruction; otherwise one wave per detector row, one pixel per lane.
+    __device__ __forceinline__ void stage_box(const BpParams& g, const Box& b, float* lds_box, uint32_t wave,
+                                              uint32_t n_waves, uint32_t lane)
+    {
+        if(g.stage_vec4)
+        {
+            const uint32_t n4 = static_cast<uint32_t>(b.bw) >> 2; // groups of 4 per row
+            if(n4 == 0u)
+                return;
+            const uint32_t rows_per_pass = n4 <= 64u ? 64u / n4 : 1u; // rows one wave-instruction covers
+            const uint32_t lr = n4 <= 64u ? lane / n4 : 0u;
+            const uint32_t lc = n4 <= 64u ? lane - lr * n4 : lane;
+            if(lr >= rows_per_pass)
+                return; // lanes beyond the last whole row of the pass idle
+            for(uint32_t r = wave * rows_per_pass + lr; r < static_cast<uint32_t>(b.bhs); r += n_waves * rows_per_pass)
+            {
+                const size_t row = static_cast<size_t>(b.by0 + static_cast<int>(r)) * g.p_pitch + static_cast<size_t>(b.bx0);
+                float* dst = lds_box + r * static_cast<uint32_t>(b.stride);
+                for(uint32_t c4 = lc; c4 < n4; c4 += 64u)
+                {
+                    float4 v;
+                    if(g.proj_f16)
+                    {
+                        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                        const half4 h = *reinterpret_cast<const half4*>(static_cast<const _Float16*>(g.proj) + row + 4u * c4);
+                        v = make_float4(static_cast<float>(h.x), static_cast<float>(h.y), static_cast<float>(h.z), static_cast<float>(h.w));
+                    }
+                    else
+                        v = *reinterpret_cast<const float4*>(static_cast<const float*>(g.proj) + row + 4u * c4);
+                    *reinterpret_cast<float4*>(dst + 4u * c4) = v;
+                }
+            }
+            return;
+        }
+        if(g.proj_f16)
+        {
+            // fp16 projection storage (BASELINE config 5): widened to fp32 here, all arithmetic stays fp32
+            for(int r = static_cast<int>(wave); r < b.bhs; r += static_cast<int>(n_waves))
+            {
+                const _Float16* src = static_cast<const _Float16*>(g.proj) + static_cast<size_t>(b.by0 + r) * g.p_pitch + b.bx0;
+                float* dst = lds_box + r * b.stride;
+                for(int c = static_cast<int>(lane); c < b.bw; c += 64)
+                    dst[c] = static_cast<float>(src[c]);
+            }
+            return;
+        }
+        for(int r = static_cast<int>(wave); r < b.bhs; r += static_cast<int>(n_waves))
+        {
+            const float* src = static_cast<const float*>(g.proj) + static_cast<size_t>(b.by0 + r) * g.p_pitch + b.bx0;
+            float* dst = lds_box + r * b.stride;
+            for(int c = static_cast<int>(lane); c < b.bw; c += 64)
+                dst[c] = src[c];
+        }
+    }
+
+    // z-invariant state of one (x,y) voxel column
+    struct Column
+    {
+        float factor, u;
+        float wx1, wx2; // x interpolation weights
+        float ymax;     // p_dim_y, or -inf when the column's x taps are outside the detector
+        int xoff;       // LDS column of the left tap, or -1 when it is not inside the staged box
+        int x1i;        // detector column of the left tap (global-memory path)
+        bool fast;      // every valid tap of this column, over the tile's whole z range, lies inside the staged box
+    };
+
+    // z_first / z_last: centred z of the tile's first and last slice. The per-slice coordinate v is a monotone
+    // function of the slice index for a fixed column (every step of its evaluation -- multiply by factor, subtract,
+    // divide by the pitch, subtract 0.5, each rounded to nearest -- is monotone), so the rows touched over the tile
+    // lie between the rows touched at its two end slices: `fast` is decided from those two evaluations alone, with
+    // the very expression the slice loop uses, and needs no error bound.
+    template <bool FD>
+    __device__ __forceinline__ Column make_column(const BpParams& g, const Box& b, uint32_t K, uint32_t L, float z_first,
+                                                  float z_last)
+    {
+        const ColConst c = column_constants<FD>(g, K, L);
+        const float x1 = floorf(c.h); // :55-58
+        const float x2 = x1 + 1.f;
+        const bool x_valid = (x1 >= 0.f) && (x2 < g.p_dim_x_f); // :65-66
+        Column col;
+        col.factor = c.factor;
+        col.u = c.u;
+        // :77-78 divide by (x2 - x1), which is exactly 1.f whenever x_valid (|x1| < 2^24): the divisions are the
+        // identity and are dropped; for an invalid column the weights are never used
+        col.wx2 = x2 - c.h;
+        col.wx1 = c.h - x1;
+        col.ymax = x_valid ? g.p_dim_y_f : -INFINITY; // folds the x validity into the y2 test
+        col.x1i = static_cast<int>(x1);
+        const int rel = col.x1i - b.bx0;
+        col.xoff = (x_valid && rel >= 0 && rel <= b.bw - 2) ? rel : -1;
+
+        const float va = v_coordinate<FD>(g, z_first, c.factor);
+        const float vb = v_coordinate<FD>(g, z_last, c.factor);
+        const bool ordered = (va == va) && (vb == vb); // no NaN
+        const int r_lo = max(static_cast<int>(floorf(fminf(va, vb))), 0);                              // valid taps start at row 0
+        const int r_hi = min(static_cast<int>(floorf(fmaxf(va, vb))), static_cast<int>(g.p_dim_y) - 2); // and end at dim_y - 2
+        const bool rows_inside = (r_lo > r_hi) || (r_lo >= b.by0 && r_hi <= b.by0 + b.bhs - 2);
+        const bool finite_factor = (c.factor - c.factor) == 0.f; // with a finite factor v is never NaN (it may overflow to inf)
+        col.fast = !x_valid || (ordered && finite_factor && col.xoff >= 0 && rows_inside);
+        return col;
+    }
+
+    // one voxel-update: src/openmp/backprojection.cpp:130-140 for slice coordinate z_m of column col
+    // FAST: the column was proven to stay inside the staged box (Column::fast), so the global-memory path and its
+    // branch are compiled out and the body is straight-line code the scheduler can overlap across voxels.
+    template <bool FD, bool FAST>
+    __device__ __forceinline__ float voxel_contribution(const BpParams& g, const Box& b, const float* lds_box, float z_m,
+                                                        const Column& col)
+    {
+        const float v = v_coordinate<FD>(g, z_m, col.factor);
+        const float y1 = floorf(v);
+        const float y2 = y1 + 1.f;
+        const int y1i = static_cast<int>(y1);
+        const int rrel = y1i - b.by0;
+        const int bhs_m2 = b.bhs - 2;
+        bool valid;
+        if(FAST)
+        {
+            // For a `fast` column "valid" (:65-68) is the same as "row and row + 1 inside the staged box": valid taps are
+            // inside by construction of `fast`, and the box is clipped to the detector, so a row pair inside it is a
+            // valid pair (floor(v) as int equals the float exactly below 2^24; a non-finite v saturates the conversion
+            // far outside; `fast` excludes a non-finite factor, the only source of NaN). One unsigned compare, with the
+            // column's x validity folded into the limit.
+            const unsigned rowlim = col.ymax > 0.f ? static_cast<unsigned>(max(b.bhs - 1, 0)) : 0u;
+            valid = static_cast<unsigned>(rrel) < rowlim;
+        }
+        else
+            valid = (y1 >= 0.f) && (y2 < col.ymax); // :67-68 (+ x validity)
+        // clamp of the row to the staged box: one median instruction (the compiler's min/max pair cannot know 0 <= hi)
+        int rc;
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(rc) : "v"(rrel), "v"(max(bhs_m2, 0)));
+        // LDS byte address of the upper left tap = row * stride4 + (box base + 4 * column): the second term is z-invariant
+        // (hoisted with the column state), so a tap pair costs one 24-bit multiply-add (rc < 2^12, stride4 < 2^16;
+        // v_mul_lo_u32 is quarter rate) and the row below one add. Integer addresses keep the compiler from adding the
+        // (zero) link-time base of the dynamic LDS array to every access.
+        using lds_cptr = const __attribute__((address_space(3))) float*;
+        const int stride4 = b.stride << 2;
+        const uint32_t xaddr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_box)) + (static_cast<uint32_t>(max(col.xoff, 0)) << 2);
+        const uint32_t a1 = static_cast<uint32_t>(__mul24(rc, stride4)) + xaddr;
+        const uint32_t a2 = a1 + static_cast<uint32_t>(stride4);
+        lds_cptr r1 = reinterpret_cast<lds_cptr>(a1);
+        lds_cptr r2 = reinterpret_cast<lds_cptr>(a2);
+        float q11 = r1[0];
+        float q21 = r1[1];
+        float q12 = r2[0];
+        float q22 = r2[1];
+        if(!FAST)
+        {
+            const bool inbox = col.xoff >= 0 && rrel >= 0 && rrel <= bhs_m2;
+            if(valid && !inbox)
+            {
+                // tap outside the staged box: read the detector directly (valid => in bounds). The volatile reads in
+                // read_pixel keep the compiler from merging these loads with the LDS reads into flat loads
+                const size_t at = static_cast<size_t>(y1i) * g.p_pitch + col.x1i;
+                q11 = read_pixel(g, at);
+                q21 = read_pixel(g, at + 1);
+                q12 = read_pixel(g, at + g.p_pitch);
+                q22 = read_pixel(g, at + g.p_pitch + 1);
+            }
+        }
+        const float interp_y1 = col.wx2 * q11 + col.wx1 * q21; // :77
+        const float interp_y2 = col.wx2 * q12 + col.wx1 * q22; // :78
+        // :80 divides by (y2 - y1) == 1.f exactly whenever valid -- dropped, as above.
+        // For a valid tap (v >= 0) both v - y1 and y2 - v are exact: below 1 they are v and RN(1 - v), from 1 up multiples
+        // of ulp(v) >= 2^-23 inside [0, 1]. So y2 - v == 1 - (v - y1) bit for bit, and the fast path (which does not need y2
+        // for its validity test) saves the addition; for an invalid tap the value is discarded below.
+        const float wy1 = v - y1;
+        const float wy2 = FAST ? 1.f - wy1 : y2 - v;
+        float det = wy2 * interp_y1 + wy1 * interp_y2;
+        det = valid ? det : 0.f;         // :71
+        return 0.5f * det * col.u * col.u; // :140
+    }
+
+    // --------------------------------------------------------------------------------------------
+    // Fused kernel (extension: paris_hip_backproject_batch). One launch adds n_proj projections: a lane keeps its
+    // 4 x TZ voxels in registers, and for every projection in turn the workgroup stages that projection's box,
+    // rebuilds the column state and adds the TZ contributions -- in projection order, so every voxel sees exactly
+    // the additions, in exactly the order, of n_proj single launches (bit-identical), while the volume is read
+    // and written once per batch: 8 / n_proj bytes per voxel-update. With the HBM term gone the kernel is bound by
+    // vector ALU issue (about 40 instructions per voxel-update plus the per-projection column setup).
+    // --------------------------------------------------------------------------------------------
+    constexpr int FUSED_MAX = 32;
+
+    struct FusedParams
+    {
+        BpParams g;           // proj = first projection; sin/cos overwritten per projection
+        uint32_t n_proj;
+        uint32_t proj_stride; // pixels between consecutive projections
+        float sin_phi[FUSED_MAX];
+        float cos_phi[FUSED_MAX];
+    };
+}
+
+// backproject_fused.hip: launches bp_fused_kernel<tz, nt, fd> for *fused_params (a FusedParams; passed untyped because the
+// type has internal linkage in each translation unit -- both see the one definition above). tz is 8 or 16.
+void paris_hip_bp_launch_fused(const void* fused_params, int tz, bool nt, bool fd, hipStream_t stream);
+
+#endif
