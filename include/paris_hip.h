@@ -201,8 +201,8 @@ int paris_hip_backproject_f16(paris_hip_ctx* ctx, const uint16_t* d_p, size_t p_
 /* Extension (no reference counterpart): backprojects n_proj projections per launch (fused kernel, up to 32 per
  * launch, more are split); projection i is at d_p + i * p_stride_bytes. Every voxel's sum is accumulated in
  * projection order in registers, so the result is bit-identical to n_proj successive paris_hip_backproject calls
- * while the volume is read and written once per launch: 8 / n_proj bytes of HBM traffic per voxel-update. Volumes
- * that are not 16-byte aligned with dim_x % 4 == 0 take one launch per projection. */
+ * while the volume is read and written once per launch: 8 / n_proj bytes of HBM traffic per voxel-update. Any volume
+ * width and alignment; n_proj == 1 is the single-projection kernel. */
 int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, size_t p_stride_bytes,
                                 uint32_t n_proj, uint32_t p_dim_x, uint32_t p_dim_y, float* d_v,
                                 uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,

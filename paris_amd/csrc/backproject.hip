@@ -634,11 +634,18 @@ extern "C" int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p,
     if(n_proj == 0)
         return paris_hip_finish(ctx);
 
-    // The fused kernel needs 16-byte lanes; any other volume, and the cross-check variants, take the sequence of
-    // single-projection launches that the fused kernel is defined to equal.
-    // A single projection is the tile kernel's case (memory bound, nothing to fuse).
-    const bool fused_ok = n_proj > 1 && (ctx->bp_variant == 0 || ctx->bp_variant == 4) && d_v != nullptr
-                          && lane_width(d_v, v_dim_x) == 4 && (ctx->bp_vx == 0 || ctx->bp_vx == 4);
+    // The cross-check variants take the sequence of single-projection launches that the fused kernel is defined to
+    // equal, and so does a single projection: that is the tile kernel's case (memory bound, nothing to fuse).
+    // Lane width of the fused kernel: 2 voxels along x (16 slices x 2 accumulators leave room for five waves per SIMD,
+    // which its latency-bound loop needs: 1.30 TVox/s against 1.16 with 4 voxels per lane at three waves), 1 voxel for
+    // volumes whose rows are not 8-byte aligned; the tuning knob can ask for 4 or 1.
+    const int width = d_v != nullptr ? lane_width(d_v, v_dim_x) : 1;
+    int fused_vx = width >= 2 ? 2 : 1;
+    if(ctx->bp_vx == 4 && width == 4)
+        fused_vx = 4;
+    else if(ctx->bp_vx == 1)
+        fused_vx = 1;
+    const bool fused_ok = n_proj > 1 && (ctx->bp_variant == 0 || ctx->bp_variant == 4) && d_v != nullptr;
     if(!fused_ok)
     {
         const unsigned saved = ctx->flags;
@@ -678,7 +685,7 @@ extern "C" int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p,
         }
         const size_t ev = static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size());
         PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
-        paris_hip_bp_launch_fused(&fp, tz16 ? 16 : 8, nt, fd, ctx->stream);
+        paris_hip_bp_launch_fused(&fp, fused_vx, tz16 ? 16 : 8, nt, fd, ctx->stream);
         PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
         ++ctx->bp_launches;
     }

@@ -10,16 +10,23 @@ namespace
 {
     // (Double-buffering the box with the next projection's loads kept in flight was measured slower: the kernel is
     // bound by vector ALU issue, not by staging latency, and the extra live registers cost occupancy.)
-    // Waves per SIMD the fused kernel is compiled for: its loop is bound by LDS/ALU latency, not by issue slots, so a
-    // third resident wave (<= 168 VGPRs, a few cold-path spills) is worth +10 % over the compiler's unconstrained 196.
+    // Waves per SIMD the fused kernel is compiled for. Its loop is bound by LDS / ALU latency until about four waves are
+    // resident, so the register budget decides: 4 voxels per lane x 16 slices need 196 VGPRs unconstrained (2 waves,
+    // 0.93 TVox/s on the 2048^3 volume), 168 with a few cold-path spills (3 waves, 1.16); 2 voxels per lane fit 5 waves
+    // (96 VGPRs, 1.30); 1 voxel per lane fits 7 but pays more staging per voxel (1.16). The base value below is the
+    // 4-voxel / 16-slice case; narrower lanes and 8-slice tiles add to it.
 #ifndef PARIS_FUSED_WAVES
 #define PARIS_FUSED_WAVES 3
 #endif
-    template <int TZ, bool NT, bool FD>
-    __global__ void __launch_bounds__(256, PARIS_FUSED_WAVES) bp_fused_kernel(const FusedParams fp)
+    template <int VX, int TZ, bool NT, bool FD>
+    __global__ void __launch_bounds__(256, PARIS_FUSED_WAVES + (VX == 2 ? 2 : VX == 1 ? 4 : 0) + (TZ == 8 ? 1 : 0)) bp_fused_kernel(const FusedParams fp)
     {
         extern __shared__ __attribute__((aligned(16))) float lds[];
         BpParams g = fp.g;
+        using vec = typename vec_of<VX>::type;
+        constexpr uint32_t XL = 64u / VX; // lanes along x per wave
+        constexpr uint32_t RW = VX;       // volume rows per wave
+        constexpr uint32_t TY = 4u * RW;
 
         const uint32_t tid = threadIdx.x;
         const uint32_t lane = tid & 63u;
@@ -29,25 +36,25 @@ namespace
         if(!tile_of_block(g, blockIdx.x, bx, by, bz))
             return;
         const uint32_t k0 = bx * 64u;
-        const uint32_t l0 = by * 16u;
+        const uint32_t l0 = by * TY;
         const uint32_t m0 = bz * TZ;
         const uint32_t k1 = min(k0 + 63u, g.v_dim_x - 1u);
-        const uint32_t l1 = min(l0 + 15u, g.v_dim_y - 1u);
+        const uint32_t l1 = min(l0 + TY - 1u, g.v_dim_y - 1u);
         const uint32_t m1 = min(m0 + TZ - 1u, g.v_dim_z - 1u);
         const uint32_t mcount = m1 - m0 + 1u;
 
-        const uint32_t xq = lane & 15u, yy = lane >> 4;
-        const uint32_t k = k0 + xq * 4u;
-        const uint32_t l = l0 + wave * 4u + yy;
+        const uint32_t xq = lane % XL, yy = lane / XL;
+        const uint32_t k = k0 + xq * VX;
+        const uint32_t l = l0 + wave * RW + yy;
         const bool active = k < g.v_dim_x && l < g.v_dim_y; // inactive lanes still take part in the barriers
 
         const size_t slice = static_cast<size_t>(g.v_dim_x) * g.v_dim_y;
         float* vp = g.vol + (static_cast<size_t>(m0) * g.v_dim_y + l) * g.v_dim_x + k;
-        float4 acc[TZ];
+        vec acc[TZ];
 #pragma unroll
         for(int z = 0; z < TZ; ++z)
             if(active && static_cast<uint32_t>(z) < mcount)
-                acc[z] = load_voxels<4, NT>(vp + z * slice);
+                acc[z] = load_voxels<VX, NT>(vp + z * slice);
 
         const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
         const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
@@ -64,10 +71,10 @@ namespace
             __syncthreads();
             if(active)
             {
-                Column col[4];
+                Column col[VX];
                 bool all_fast = true;
 #pragma unroll
-                for(int j = 0; j < 4; ++j)
+                for(int j = 0; j < VX; ++j)
                 {
                     col[j] = make_column<FD>(g, box, g.k_off + k + j, g.l_off + l, z_first, z_last);
                     all_fast = all_fast && col[j].fast;
@@ -81,10 +88,9 @@ namespace
                         if(FULL || static_cast<uint32_t>(z) < mcount) // uniform; no break, so acc stays in registers
                         {
                             const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + z) * g.l_vx_z; // :118
-                            acc[z].x += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[0]);
-                            acc[z].y += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[1]);
-                            acc[z].z += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[2]);
-                            acc[z].w += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[3]);
+#pragma unroll
+                            for(int j = 0; j < VX; ++j)
+                                elem<VX>(acc[z], j) += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[j]);
                         }
                     }
                 };
@@ -99,40 +105,46 @@ namespace
 #pragma unroll
         for(int z = 0; z < TZ; ++z)
             if(active && static_cast<uint32_t>(z) < mcount)
-                store_voxels<4, NT>(vp + z * slice, acc[z]);
+                store_voxels<VX, NT>(vp + z * slice, acc[z], g.store_sc1 != 0u);
     }
 
-    template <int TZ, bool NT, bool FD>
+    template <int VX, int TZ, bool NT, bool FD>
     void launch_fused(FusedParams& fp, hipStream_t stream)
     {
         BpParams& g = fp.g;
         g.tz = TZ;
         g.ntx = (g.v_dim_x + 63u) / 64u;
-        g.nty = (g.v_dim_y + 15u) / 16u;
+        g.nty = (g.v_dim_y + 4u * VX - 1u) / (4u * VX);
         g.ntz = (g.v_dim_z + TZ - 1u) / TZ;
         uint32_t blocks = grid_blocks(g);
-        hipLaunchKernelGGL((bp_fused_kernel<TZ, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, fp);
+        hipLaunchKernelGGL((bp_fused_kernel<VX, TZ, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, fp);
     }
 
-    template <int TZ>
+    template <int VX, int TZ>
     void launch_fused_flags(FusedParams& fp, bool nt, bool fd, hipStream_t stream)
     {
         if(nt && fd)
-            launch_fused<TZ, true, true>(fp, stream);
+            launch_fused<VX, TZ, true, true>(fp, stream);
         else if(nt)
-            launch_fused<TZ, true, false>(fp, stream);
+            launch_fused<VX, TZ, true, false>(fp, stream);
         else if(fd)
-            launch_fused<TZ, false, true>(fp, stream);
+            launch_fused<VX, TZ, false, true>(fp, stream);
         else
-            launch_fused<TZ, false, false>(fp, stream);
+            launch_fused<VX, TZ, false, false>(fp, stream);
     }
 }
 
-void paris_hip_bp_launch_fused(const void* fused_params, int tz, bool nt, bool fd, hipStream_t stream)
+void paris_hip_bp_launch_fused(const void* fused_params, int vx, int tz, bool nt, bool fd, hipStream_t stream)
 {
     FusedParams fp = *static_cast<const FusedParams*>(fused_params);
-    if(tz == 8)
-        launch_fused_flags<8>(fp, nt, fd, stream);
+    if(vx == 1) // tz 8 is not built for this width
+        launch_fused_flags<1, 16>(fp, nt, fd, stream);
+    else if(vx == 2 && tz == 8)
+        launch_fused_flags<2, 8>(fp, nt, fd, stream);
+    else if(vx == 2)
+        launch_fused_flags<2, 16>(fp, nt, fd, stream);
+    else if(tz == 8)
+        launch_fused_flags<4, 8>(fp, nt, fd, stream);
     else
-        launch_fused_flags<16>(fp, nt, fd, stream);
+        launch_fused_flags<4, 16>(fp, nt, fd, stream);
 }

@@ -477,7 +477,7 @@ namespace
 }
 
 // backproject_fused.hip: launches bp_fused_kernel<tz, nt, fd> for *fused_params (a FusedParams; passed untyped because the
-// type has internal linkage in each translation unit -- both see the one definition above). tz is 8 or 16.
-void paris_hip_bp_launch_fused(const void* fused_params, int tz, bool nt, bool fd, hipStream_t stream);
+// type has internal linkage in each translation unit -- both see the one definition above). vx (voxels per lane along x) is 2 or 4, tz 8 or 16.
+void paris_hip_bp_launch_fused(const void* fused_params, int vx, int tz, bool nt, bool fd, hipStream_t stream);
 
 #endif

@@ -473,20 +473,23 @@ def test_make_subvolume_information(be):
     assert info.geo.dim_z * 8192 * 8192 * 4 < 288e9
 
 
-@pytest.mark.parametrize("n_proj,tz,lds_bytes", [(9, 0, 0), (40, 0, 0), (9, 8, 0), (5, 0, 1024), (33, 8, 4096)])
-def test_backproject_fused_batch_bit_exact(be, oracle, n_proj, tz, lds_bytes):
+@pytest.mark.parametrize("n_proj,tz,lds_bytes,vx,x2", [(9, 0, 0, 0, 82), (40, 0, 0, 0, 82), (9, 8, 0, 0, 82), (5, 0, 1024, 0, 82),
+                                                         (33, 8, 4096, 0, 82), (9, 0, 0, 4, 82), (9, 8, 0, 4, 82), (9, 0, 0, 1, 82),
+                                                         (9, 0, 0, 0, 81), (7, 0, 1024, 0, 79), (9, 0, 0, 0, 80)])
+def test_backproject_fused_batch_bit_exact(be, oracle, n_proj, tz, lds_bytes, vx, x2):
     """paris_hip_backproject_batch's fused kernel (n_proj projections per launch, split at 32) adds the projections
     to every voxel in projection order: bit-identical to the oracle's sequential loop. Partial tiles in x, y, z;
-    ROI and slab offset; both tile depths; an LDS budget that forces the global tap path."""
+    ROI and slab offset; both tile depths; an LDS budget that forces the global tap path; every lane width (default 2
+    voxels, 4 and 1 on request; odd-width volumes -- x2 = 81, 79 -- take 1, a 70-wide one 2)."""
     g = (96, 80, 0.2, 0.25, -2.5, 1.25, 150, 250, 9.0)
     det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
     nat = B.calculate_volume_geometry(det)
     full = (60, 50, 90)
     vg = B.VolumeGeometry(full[2], full[1], full[0], nat.l_vx_x * 1.1, nat.l_vx_x * 1.6, nat.l_vx_x * 1.4)
     ovg = oracle.VolumeGeometry(full[2], full[1], full[0], vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
-    roi = B.RegionOfInterest(10, 82, 5, 47, 6, 51)        # 72 x 42 x 45
-    oroi = oracle.RegionOfInterest(10, 82, 5, 47, 6, 51)
-    dims, v_offset = (21, 42, 72), 12                      # second part of the ROI's slices
+    roi = B.RegionOfInterest(10, x2, 5, 47, 6, 51)        # 72 x 42 x 45 for x2 = 82
+    oroi = oracle.RegionOfInterest(10, x2, 5, 47, 6, 51)
+    dims, v_offset = (21, 42, x2 - 10), 12                 # second part of the ROI's slices
     projs = [oracle.lcg_projection(96, 80, i) - np.float32(0.5) for i in range(n_proj)]
     want = np.zeros(dims, np.float32)
     for i, p in enumerate(projs):
@@ -497,7 +500,7 @@ def test_backproject_fused_batch_bit_exact(be, oracle, n_proj, tz, lds_bytes):
     be.copy_h2d(B.Projection(np.ascontiguousarray(np.concatenate(projs)), 96, 80 * n_proj), stack)
     sc = [B.stage_angle(det, i) for i in range(n_proj)]
     d_v = be.make_volume_device(dims[2], dims[1], dims[0])
-    be.set_backproject_tuning(tz=tz, lds_bytes=lds_bytes)
+    be.set_backproject_tuning(vx=vx, tz=tz, lds_bytes=lds_bytes)
     try:
         be.backproject_batch(stack.ptr, stack.pitch, stack.pitch * 80, n_proj, 96, 80, d_v, v_offset, det, vg, True, roi,
                              [s for s, _ in sc], [c for _, c in sc], det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
@@ -843,7 +846,7 @@ def test_backproject_random_geometries_bit_exact(be, oracle, seed):
         assert_bit_equal(volume_to_host(be, d_v), want[z2:z2 + dz2])
         be.free(d_v)
 
-    if dims[2] % 4 == 0:  # the fused batch entry on the same case
+    if True:  # the fused batch entry on the same case (lane width 2 or 1 by the volume's alignment)
         stack = be.make_projection_device(n_row, n_col * n_proj)
         be.copy_h2d(B.Projection(np.ascontiguousarray(np.concatenate(projs)), n_row, n_col * n_proj), stack)
         sc = [B.stage_angle(det, i, True, angles[i]) for i in range(n_proj)]
