@@ -12,14 +12,14 @@ namespace
     // bound by vector ALU issue, not by staging latency, and the extra live registers cost occupancy.)
     // Waves per SIMD the fused kernel is compiled for. Its loop is bound by LDS / ALU latency until about four waves are
     // resident, so the register budget decides: 4 voxels per lane x 16 slices need 196 VGPRs unconstrained (2 waves,
-    // 0.93 TVox/s on the 2048^3 volume), 168 with a few cold-path spills (3 waves, 1.16); 2 voxels per lane fit 5 waves
-    // (96 VGPRs, 1.30); 1 voxel per lane fits 7 but pays more staging per voxel (1.16). The base value below is the
+    // 0.93 TVox/s on the 2048^3 volume), 168 with a few cold-path spills (3 waves, 1.16); 2 voxels per lane run at 4 waves
+    // without spills (1.30; a fifth wave adds nothing); 1 voxel per lane fits 7 but pays more staging per voxel (1.16). The base value below is the
     // 4-voxel / 16-slice case; narrower lanes and 8-slice tiles add to it.
 #ifndef PARIS_FUSED_WAVES
 #define PARIS_FUSED_WAVES 3
 #endif
     template <int VX, int TZ, bool NT, bool FD>
-    __global__ void __launch_bounds__(256, PARIS_FUSED_WAVES + (VX == 2 ? 2 : VX == 1 ? 4 : 0) + (TZ == 8 ? 1 : 0)) bp_fused_kernel(const FusedParams fp)
+    __global__ void __launch_bounds__(256, PARIS_FUSED_WAVES + (VX == 2 ? 1 : VX == 1 ? 4 : 0) + (TZ == 8 ? 1 : 0)) bp_fused_kernel(const FusedParams fp)
     {
         extern __shared__ __attribute__((aligned(16))) float lds[];
         BpParams g = fp.g;
@@ -58,6 +58,8 @@ namespace
 
         const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
         const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
+        // (Keeping the loop constants of the per-voxel chain in VGPRs -- a plain fp32 multiply / add issues 1.6x faster in
+        // isolation when no source is a scalar register, tools/pkbench.hip -- was measured: no gain in this instruction mix.)
         const char* base = static_cast<const char*>(fp.g.proj);
         const size_t px = g.proj_f16 ? 2u : 4u;
         for(uint32_t p = 0; p < fp.n_proj; ++p)
