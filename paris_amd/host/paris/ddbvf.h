@@ -17,6 +17,8 @@
 #include <string>
 #include <system_error>
 
+#include <unistd.h>
+
 namespace paris
 {
     namespace ddbvf
@@ -66,12 +68,26 @@ namespace paris
                 throw std::runtime_error{"ddbvf::write(): Attempting to save volume to file with wrong dimensions"};
             const auto slice = static_cast<std::uint64_t>(dim_x) * dim_y * sizeof(float);
             const auto pos = static_cast<std::uint64_t>(first_pos) + slice * first;
-            if(fseeko(h->file, static_cast<off_t>(pos), SEEK_SET) != 0)
-                throw std::system_error{errno, std::generic_category(), "ddbvf::write(): seek"};
-            const auto n = static_cast<std::size_t>(dim_x) * dim_y * dim_z_slab;
-            if(std::fwrite(voxels, sizeof(float), n, h->file) != n)
-                throw std::system_error{errno, std::generic_category(), "ddbvf::write()"};
-            std::fflush(h->file);
+            // positioned writes on the descriptor: no shared stream position, so slabs of different device threads can be
+            // written concurrently (the reference's fseek + fwrite needs the mutex of src/sink.cpp:79-80)
+            const int fd = fileno(h->file);
+            const auto* bytes = reinterpret_cast<const char*>(voxels);
+            auto left = static_cast<std::uint64_t>(dim_x) * dim_y * dim_z_slab * sizeof(float);
+            auto at = pos;
+            while(left != 0)
+            {
+                const auto chunk = left < (std::uint64_t{1} << 30) ? static_cast<std::size_t>(left) : (std::size_t{1} << 30);
+                const auto done = ::pwrite(fd, bytes, chunk, static_cast<off_t>(at));
+                if(done < 0)
+                {
+                    if(errno == EINTR)
+                        continue;
+                    throw std::system_error{errno, std::generic_category(), "ddbvf::write()"};
+                }
+                bytes += done;
+                at += static_cast<std::uint64_t>(done);
+                left -= static_cast<std::uint64_t>(done);
+            }
         }
     }
 }

@@ -4,7 +4,6 @@
 #ifndef PARIS_AMD_HOST_SINK_H_
 #define PARIS_AMD_HOST_SINK_H_
 
-#include <mutex>
 #include <string>
 
 #include <sys/stat.h>
@@ -55,14 +54,12 @@ namespace paris
 
         auto file_path() const -> std::string { return path_ + ".ddbvf"; }
 
-        // host voxels of one slab starting at global slice `first`; serialised like src/sink.cpp:79-81
+        // host voxels of one slab (or a chunk of it) starting at global slice `first`. The reference serialises this with a
+        // static mutex (src/sink.cpp:79-81) because its writer moves a shared stream position; ddbvf::write uses positioned
+        // writes, so device threads write their disjoint slice ranges concurrently.
         auto save(const float* voxels, std::uint32_t dim_x, std::uint32_t dim_y, std::uint32_t dim_z, std::uint32_t first) -> void
         {
-            try
-            {
-                std::lock_guard<std::mutex> lock{mutex_};
-                ddbvf::write(handle_, voxels, dim_x, dim_y, dim_z, first);
-            }
+            try { ddbvf::write(handle_, voxels, dim_x, dim_y, dim_z, first); }
             catch(const std::system_error& se) { throw stage_runtime_error{std::string{"sink::save() failed: "} + se.what()}; }
             catch(const std::runtime_error& re) { throw stage_runtime_error{std::string{"sink::save() failed: "} + re.what()}; }
         }
@@ -71,7 +68,6 @@ namespace paris
         std::string path_;
         ddbvf::handle_type handle_;
         volume_geometry vol_geo_;
-        std::mutex mutex_;
     };
 }
 
