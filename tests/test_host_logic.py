@@ -106,6 +106,22 @@ def test_invalid_arguments():
     assert L.paris_hip_weight(None, None, 0, 0, 0, 0, 0, 0, 0, 0) == _lib.ERROR_INVALID_ARGUMENT
     assert L.paris_hip_calculate_volume_geometry(None, None) == _lib.ERROR_INVALID_ARGUMENT
     assert b"invalid argument" in L.paris_hip_strerror(_lib.ERROR_INVALID_ARGUMENT)
+    # the extensions: null ctx / null outputs are rejected before anything touches a device
+    assert L.paris_hip_upload_projection(None, None, 0, None, 0, 0, 0) == _lib.ERROR_INVALID_ARGUMENT
+    assert L.paris_hip_weight_rows(None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == _lib.ERROR_INVALID_ARGUMENT
+    assert L.paris_hip_stage_filter_rows(None, None, 0, 0, 0, 0, 0, None) == _lib.ERROR_INVALID_ARGUMENT
+    det = B.DetectorGeometry(64, 48, 0.2, 0.25, 1.5, -0.75, 100, 200, 45)
+    vg = B.calculate_volume_geometry(det)
+    first, count = C.c_uint32(), C.c_uint32()
+    assert L.paris_hip_slab_row_band(C.byref(det), C.byref(vg), 67, 67, 61, 0, 0, None, None, C.byref(count)) == _lib.ERROR_INVALID_ARGUMENT
+    assert L.paris_hip_slab_row_band(C.byref(det), C.byref(vg), 67, 67, 61, 0, 1, None, C.byref(first), C.byref(count)) \
+        == _lib.ERROR_INVALID_ARGUMENT                       # ROI enabled but not given
+    assert B.slab_row_band(det, vg, 67, 67, 0) == (0, 0)    # an empty slab reads nothing
+    assert B.slab_row_band(det, vg, 67, 67, 61) == (0, 48)  # the whole field of view reads the whole detector
+    # a source inside the volume's circle: no bound exists, the whole detector is reported
+    near = B.DetectorGeometry(64, 48, 0.2, 0.25, 0.0, 0.0, 3.0, 200, 45)
+    big = B.VolumeGeometry(64, 64, 64, 0.2, 0.2, 0.2)
+    assert B.slab_row_band(near, big, 64, 64, 4, 10) == (0, 48)
 
 
 def test_product_does_not_import_the_oracle():
