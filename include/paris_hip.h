@@ -210,6 +210,20 @@ int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p, size_t p_p
                                 int enable_roi, const paris_region_of_interest* roi, const float* sin_phi,
                                 const float* cos_phi, float delta_s, float delta_t);
 
+/* Extension: deferred backprojection. With depth n > 1 (n <= 64), paris_hip_backproject copies its projection into a ring
+ * owned by the ctx (stream-ordered device-to-device copy: the caller may reuse its buffer as after any asynchronous
+ * call) and returns; the pending projections are added by ONE fused launch, in call order and bit-identical to n
+ * single launches, when n are pending, when a call with another volume, slab, geometry or ROI arrives, and before
+ * every entry point that observes or changes a volume, completes work or changes how backprojection runs
+ * (paris_hip_ctx_synchronize, _fence_record, _memcpy_volume_*, _memset_volume, _free, _backproject_f16, _backproject_batch,
+ * the timing and tuning calls, paris_hip_flush). The volume is then read and written once per n projections instead of
+ * once per projection. Two caveats: work the caller enqueues on the ctx's stream OUTSIDE this API does not see deferred
+ * projections (call paris_hip_flush first), and paris_hip_ctx_destroy discards what is still pending. Depth 1 (the
+ * default) is immediate execution. The C++ mirror paris::hip enables depth 16, so PARIS's unchanged per-projection loop
+ * (src/main.cpp:98-105) runs at the fused kernel's rate. */
+int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t depth);
+int paris_hip_flush(paris_hip_ctx* ctx);
+
 /* ---- stage wrappers and geometry (host code of the hot path) ----------------------------------------
  * The reference derives the kernels' scalar arguments in backend-neutral wrappers and caches them in
  * function-local statics; these entry points restate them per call (no statics). */

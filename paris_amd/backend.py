@@ -291,6 +291,13 @@ class Backend:
         check(self._L.paris_hip_set_backproject_slice_shape(self._ctx, waves, row_groups),
               "paris_hip_set_backproject_slice_shape")
 
+    def set_backproject_deferral(self, depth):
+        """depth > 1: backproject() calls are snapshotted and added by one fused launch per `depth` calls (bit-identical)"""
+        check(self._L.paris_hip_set_backproject_deferral(self._ctx, depth), "paris_hip_set_backproject_deferral")
+
+    def flush(self):
+        check(self._L.paris_hip_flush(self._ctx), "paris_hip_flush")
+
     def set_backproject_tuning(self, vx=0, unroll=0, tz=0, lds_bytes=0):
         check(self._L.paris_hip_set_backproject_tuning(self._ctx, vx, unroll, tz, lds_bytes),
               "paris_hip_set_backproject_tuning")

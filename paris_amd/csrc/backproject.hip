@@ -567,15 +567,121 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
     return paris_hip_finish(ctx);
 }
 
-extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, uint32_t p_dim_x,
-                                     uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y,
-                                     uint32_t v_dim_z, uint32_t v_offset, const paris_detector_geometry* det_geo,
-                                     const paris_volume_geometry* vol_geo, int enable_roi,
-                                     const paris_region_of_interest* roi, float sin_phi, float cos_phi,
-                                     float delta_s, float delta_t)
+// ---- deferred backprojection -------------------------------------------------------------------------------------
+// With a deferral depth n > 1 a paris_hip_backproject call snapshots its projection into a device ring (stream-ordered
+// copy, so the caller may reuse its buffer as usual) and returns; n pending calls -- or fewer when a call with other
+// volume / geometry arguments arrives or when the volume is observed -- are added by ONE fused launch in call order,
+// which is bit-identical to n single launches and moves 8/n instead of 8 bytes per voxel-update.
+static int batch_impl(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, size_t p_stride_bytes, uint32_t n_proj, uint32_t p_dim_x,
+                      uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
+                      const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
+                      const paris_region_of_interest* roi, const float* sin_phi, const float* cos_phi, float delta_s, float delta_t);
+
+int paris_hip_flush_deferred(paris_hip_ctx* ctx)
 {
-    return backproject_impl(ctx, d_p, false, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
-                            vol_geo, enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
+    if(ctx == nullptr || ctx->defer_count == 0)
+        return PARIS_HIP_SUCCESS;
+    const uint32_t n = ctx->defer_count;
+    ctx->defer_count = 0; // first: batch_impl may fall back to single launches, which must not be deferred again
+    const uint32_t depth = ctx->defer_depth;
+    ctx->defer_depth = 1;
+    const int rc = batch_impl(ctx, ctx->defer_ring, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
+                              ctx->defer_dim_y, ctx->key_v, ctx->key_dims[0], ctx->key_dims[1], ctx->key_dims[2], ctx->key_dims[3],
+                              &ctx->key_det, &ctx->key_vol, ctx->key_enable_roi, &ctx->key_roi, ctx->defer_sin.data(),
+                              ctx->defer_cos.data(), ctx->key_delta_s, ctx->key_delta_t);
+    ctx->defer_depth = depth;
+    return rc;
+}
+
+static int defer_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, uint32_t p_dim_x, uint32_t p_dim_y, float* d_v,
+                             uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
+                             const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
+                             const paris_region_of_interest* roi, float sin_phi, float cos_phi, float delta_s, float delta_t)
+{
+    // the checks of an immediate call, so that a bad argument is reported by the call that made it
+    BpParams g;
+    bool fd = false, skip = false;
+    if(int rc = fill_params(ctx, d_p, false, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
+                            enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t, g, fd, skip))
+        return rc;
+    if(skip)
+        return paris_hip_finish(ctx);
+    const paris_region_of_interest no_roi{};
+    const paris_region_of_interest& r = enable_roi ? *roi : no_roi;
+    const uint32_t dims[4] = {v_dim_x, v_dim_y, v_dim_z, v_offset};
+    const bool same = ctx->defer_count != 0 && ctx->key_v == d_v && std::memcmp(ctx->key_dims, dims, sizeof(dims)) == 0
+                      && std::memcmp(&ctx->key_det, det_geo, sizeof(*det_geo)) == 0 && std::memcmp(&ctx->key_vol, vol_geo, sizeof(*vol_geo)) == 0
+                      && ctx->key_enable_roi == (enable_roi ? 1 : 0) && std::memcmp(&ctx->key_roi, &r, sizeof(r)) == 0
+                      && std::memcmp(&ctx->key_delta_s, &delta_s, sizeof(float)) == 0 && std::memcmp(&ctx->key_delta_t, &delta_t, sizeof(float)) == 0
+                      && ctx->defer_dim_x == p_dim_x && ctx->defer_dim_y == p_dim_y;
+    if(!same)
+    {
+        if(int rc = paris_hip_flush_deferred(ctx))
+            return rc;
+        if(ctx->defer_dim_x != p_dim_x || ctx->defer_dim_y != p_dim_y || ctx->defer_slots < ctx->defer_depth)
+        {
+            if(ctx->defer_ring != nullptr)
+            {
+                PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream)); // a launch may still read the old ring
+                PARIS_HIP_TRY(hipFree(ctx->defer_ring));
+                ctx->defer_ring = nullptr;
+            }
+            ctx->defer_pitch = (static_cast<size_t>(p_dim_x) * sizeof(float) + 255u) / 256u * 256u;
+            PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->defer_ring), ctx->defer_pitch * p_dim_y * ctx->defer_depth));
+            ctx->defer_dim_x = p_dim_x;
+            ctx->defer_dim_y = p_dim_y;
+            ctx->defer_slots = ctx->defer_depth;
+        }
+        ctx->key_v = d_v;
+        std::memcpy(ctx->key_dims, dims, sizeof(dims));
+        ctx->key_det = *det_geo;
+        ctx->key_vol = *vol_geo;
+        ctx->key_enable_roi = enable_roi ? 1 : 0;
+        ctx->key_roi = r;
+        ctx->key_delta_s = delta_s;
+        ctx->key_delta_t = delta_t;
+        ctx->defer_sin.assign(ctx->defer_depth, 0.f);
+        ctx->defer_cos.assign(ctx->defer_depth, 0.f);
+    }
+    char* slot = reinterpret_cast<char*>(ctx->defer_ring) + ctx->defer_pitch * p_dim_y * ctx->defer_count;
+    PARIS_HIP_TRY(hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * sizeof(float), p_dim_y,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->defer_sin[ctx->defer_count] = sin_phi;
+    ctx->defer_cos[ctx->defer_count] = cos_phi;
+    if(++ctx->defer_count == ctx->defer_depth)
+        return paris_hip_flush_deferred(ctx);
+    return paris_hip_finish(ctx);
+}
+
+extern "C" int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t depth)
+{
+    if(ctx == nullptr || depth == 0 || depth > 64)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
+    ctx->defer_depth = depth;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_flush(paris_hip_ctx* ctx)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    return paris_hip_flush_deferred(ctx);
+}
+
+extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, uint32_t p_dim_x,
+                                     uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z,
+                                     uint32_t v_offset, const paris_detector_geometry* det_geo,
+                                     const paris_volume_geometry* vol_geo, int enable_roi,
+                                     const paris_region_of_interest* roi, float sin_phi, float cos_phi, float delta_s,
+                                     float delta_t)
+{
+    if(ctx != nullptr && ctx->defer_depth > 1 && (ctx->bp_variant == 0 || ctx->bp_variant == 4))
+        return defer_backproject(ctx, d_p, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
+                                 enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
+    return backproject_impl(ctx, d_p, false, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
+                            enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
 }
 
 extern "C" int paris_hip_backproject_f16(paris_hip_ctx* ctx, const uint16_t* d_p, size_t p_pitch, uint32_t p_dim_x,
@@ -585,6 +691,8 @@ extern "C" int paris_hip_backproject_f16(paris_hip_ctx* ctx, const uint16_t* d_p
                                          const paris_region_of_interest* roi, float sin_phi, float cos_phi,
                                          float delta_s, float delta_t)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     return backproject_impl(ctx, d_p, true, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
                             vol_geo, enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
 }
@@ -628,6 +736,17 @@ extern "C" int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p,
                                            const paris_volume_geometry* vol_geo, int enable_roi,
                                            const paris_region_of_interest* roi, const float* sin_phi,
                                            const float* cos_phi, float delta_s, float delta_t)
+{
+    if(int rc = paris_hip_flush_deferred(ctx)) // keeps the call order of deferred and explicit batches
+        return rc;
+    return batch_impl(ctx, d_p, p_pitch, p_stride_bytes, n_proj, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
+                      vol_geo, enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
+}
+
+static int batch_impl(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, size_t p_stride_bytes, uint32_t n_proj, uint32_t p_dim_x,
+                      uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
+                      const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
+                      const paris_region_of_interest* roi, const float* sin_phi, const float* cos_phi, float delta_s, float delta_t)
 {
     if(ctx == nullptr || sin_phi == nullptr || cos_phi == nullptr || p_stride_bytes % sizeof(float) != 0)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
@@ -694,6 +813,8 @@ extern "C" int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p,
 
 extern "C" int paris_hip_last_backproject_ms(paris_hip_ctx* ctx, float* ms)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(ctx == nullptr || ms == nullptr || ctx->bp_launches == 0)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(int rc = paris_hip_bind(ctx))
@@ -706,6 +827,8 @@ extern "C" int paris_hip_last_backproject_ms(paris_hip_ctx* ctx, float* ms)
 
 extern "C" int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(ctx == nullptr || variant < 0 || variant > 4)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_variant = variant;
@@ -714,6 +837,8 @@ extern "C" int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant
 
 extern "C" int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, int nontemporal)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5 || order == 8) || nontemporal < -1 || nontemporal > 2)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_order = order;
@@ -736,6 +861,8 @@ extern "C" int paris_hip_fast_division_is_exact(paris_hip_ctx* ctx, float diviso
 
 extern "C" int paris_hip_set_backproject_vector_staging(paris_hip_ctx* ctx, int enable)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(ctx == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_stage_vec4 = enable ? 1 : 0;
@@ -744,6 +871,8 @@ extern "C" int paris_hip_set_backproject_vector_staging(paris_hip_ctx* ctx, int 
 
 extern "C" int paris_hip_set_backproject_fast_division(paris_hip_ctx* ctx, int enable)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(ctx == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_fastdiv = enable ? 1 : 0;
@@ -752,6 +881,8 @@ extern "C" int paris_hip_set_backproject_fast_division(paris_hip_ctx* ctx, int e
 
 extern "C" int paris_hip_set_backproject_slice_shape(paris_hip_ctx* ctx, int waves, int row_groups)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(ctx == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     const bool ok = (waves == 0 && row_groups == 0) || (waves == 16 && (row_groups == 4 || row_groups == 2))
@@ -765,6 +896,8 @@ extern "C" int paris_hip_set_backproject_slice_shape(paris_hip_ctx* ctx, int wav
 
 extern "C" int paris_hip_set_backproject_tuning(paris_hip_ctx* ctx, int vx, int unroll, int tz, int lds_bytes)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(ctx == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(!(vx == 0 || vx == 1 || vx == 2 || vx == 4) || !(unroll == 0 || unroll == 1 || unroll == 2 || unroll == 3 || unroll == 4))

@@ -106,6 +106,8 @@ static void destroy_events(paris_hip_ctx* ctx)
 
 extern "C" int paris_hip_backproject_timing_arm(paris_hip_ctx* ctx, uint32_t capacity)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(int rc = paris_hip_bind(ctx))
         return rc;
     if(capacity == 0 || capacity > 65536u)
@@ -129,6 +131,8 @@ extern "C" int paris_hip_backproject_timing_arm(paris_hip_ctx* ctx, uint32_t cap
 
 extern "C" int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* ms, uint32_t max_n, uint32_t* n_out)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(int rc = paris_hip_bind(ctx))
         return rc;
     if(ms == nullptr || n_out == nullptr)
@@ -155,6 +159,9 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
         (void)hipFree(kv.second.d_twiddle);
     if(ctx->d_sincos != nullptr)
         (void)hipFree(ctx->d_sincos);
+    ctx->defer_count = 0; // projections still deferred are dropped: their volume may be gone (flush or synchronize first)
+    if(ctx->defer_ring != nullptr)
+        (void)hipFree(ctx->defer_ring);
     if(ctx->stage_k != nullptr)
         (void)hipFree(ctx->stage_k);
     if(ctx->upload_stream != nullptr)
@@ -176,6 +183,8 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
 
 extern "C" int paris_hip_ctx_synchronize(paris_hip_ctx* ctx)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(int rc = paris_hip_bind(ctx))
         return rc;
     PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -216,6 +225,8 @@ extern "C" int paris_hip_fence_create(paris_hip_ctx* ctx, paris_hip_fence** out)
 
 extern "C" int paris_hip_fence_record(paris_hip_ctx* ctx, paris_hip_fence* fence)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(int rc = paris_hip_bind(ctx))
         return rc;
     if(fence == nullptr)
@@ -267,6 +278,8 @@ extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, u
 
 extern "C" int paris_hip_memset_volume(paris_hip_ctx* ctx, float* d_ptr, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(int rc = paris_hip_bind(ctx))
         return rc;
     if(d_ptr == nullptr)
@@ -298,6 +311,8 @@ extern "C" int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint3
 
 extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(int rc = paris_hip_bind(ctx))
         return rc;
     if(d_ptr == nullptr)
@@ -383,6 +398,8 @@ extern "C" int paris_hip_memcpy_projection_d2h(paris_hip_ctx* ctx, float* h_dst,
 extern "C" int paris_hip_memcpy_volume_h2d(paris_hip_ctx* ctx, float* d_dst, const float* h_src, uint32_t dim_x,
                                            uint32_t dim_y, uint32_t dim_z)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(int rc = paris_hip_bind(ctx))
         return rc;
     if(d_dst == nullptr || h_src == nullptr)
@@ -395,6 +412,8 @@ extern "C" int paris_hip_memcpy_volume_h2d(paris_hip_ctx* ctx, float* d_dst, con
 extern "C" int paris_hip_memcpy_volume_d2h(paris_hip_ctx* ctx, float* h_dst, const float* d_src, uint32_t dim_x,
                                            uint32_t dim_y, uint32_t dim_z)
 {
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
     if(int rc = paris_hip_bind(ctx))
         return rc;
     if(h_dst == nullptr || d_src == nullptr)

@@ -59,6 +59,21 @@ struct paris_hip_ctx
     float* stage_k = nullptr;
     uint32_t stage_k_size = 0;
     float stage_k_tau = 0.f;
+    // deferred backprojection (paris_hip_set_backproject_deferral): projections copied at call time into a device ring and
+    // added by one fused launch per `defer_depth` calls; the key_* fields are the arguments the pending calls share
+    uint32_t defer_depth = 1; // 1 = immediate
+    uint32_t defer_count = 0; // projections pending in the ring
+    float* defer_ring = nullptr;
+    size_t defer_pitch = 0;
+    uint32_t defer_dim_x = 0, defer_dim_y = 0, defer_slots = 0;
+    float* key_v = nullptr;
+    uint32_t key_dims[4] = {0, 0, 0, 0}; // v_dim_x, v_dim_y, v_dim_z, v_offset
+    paris_detector_geometry key_det{};
+    paris_volume_geometry key_vol{};
+    int key_enable_roi = 0;
+    paris_region_of_interest key_roi{};
+    float key_delta_s = 0.f, key_delta_t = 0.f;
+    std::vector<float> defer_sin, defer_cos;
     // device copies of the per-projection sin/cos for the batched launch
     float* d_sincos = nullptr;
     uint32_t d_sincos_cap = 0;
@@ -82,5 +97,9 @@ inline int paris_hip_bind(paris_hip_ctx* ctx)
 }
 
 int paris_hip_get_plan(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_plan** out);
+
+// backproject.hip: runs the projections pending in the deferral ring (no-op when there are none). Called by every entry
+// point that observes or changes a volume, completes work, or changes how backprojection runs.
+int paris_hip_flush_deferred(paris_hip_ctx* ctx);
 
 #endif

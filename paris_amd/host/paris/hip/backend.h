@@ -14,6 +14,10 @@
 #ifndef PARIS_AMD_HOST_HIP_BACKEND_H_
 #define PARIS_AMD_HOST_HIP_BACKEND_H_
 
+#ifndef PARIS_HIP_BACKPROJECT_DEFERRAL
+#define PARIS_HIP_BACKPROJECT_DEFERRAL 16
+#endif
+
 #include <cstddef>
 #include <cstdint>
 #include <map>
@@ -102,6 +106,11 @@ namespace paris
             {
                 paris_hip_ctx* c = nullptr;
                 detail::construction_check(paris_hip_ctx_create(d, nullptr, PARIS_HIP_CTX_SYNCHRONOUS, &c), "set_device()");
+                // PARIS calls backproject() once per projection (src/main.cpp:98-105). The library snapshots each call's
+                // projection and adds PARIS_HIP_BACKPROJECT_DEFERRAL of them with one fused launch -- bit-identical, the
+                // slab is read and written once per group instead of once per projection -- and flushes before anything
+                // observes the volume (copy_d2h, free): see paris_hip_set_backproject_deferral. 1 = one launch per call.
+                detail::construction_check(paris_hip_set_backproject_deferral(c, PARIS_HIP_BACKPROJECT_DEFERRAL), "set_device()");
                 it = s.per_device.emplace(d, std::unique_ptr<paris_hip_ctx, detail::ctx_deleter>{c}).first;
             }
             s.current = it->second.get();
