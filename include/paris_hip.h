@@ -280,7 +280,9 @@ int paris_hip_backproject_timing_arm(paris_hip_ctx* ctx, uint32_t capacity);
 int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* ms, uint32_t max_n, uint32_t* n_out);
 /* Selects the backprojection kernel: 0 = default (currently the tile kernel), 1 = one-thread-per-voxel gather kernel
  * without LDS (slow, for cross-checking), 2 = tile kernel (z-walk per workgroup), 3 = slice kernel (one slice per
- * wave; needs a 16-byte aligned volume with dim_x % 4 == 0, else falls back to 2). All give identical bits.
+ * wave; needs a 16-byte aligned volume with dim_x % 4 == 0, else falls back to 2), 4 = the fused kernel run with one
+ * projection (every slice of a tile in flight before the first store; measured 5 % slower than the tile kernel). All give
+ * identical bits.
  * paris_hip_backproject_batch uses its fused kernel under variant 0 and runs one launch per projection otherwise. */
 int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant);
 /* Tuning knobs of the LDS-staged kernel; 0 keeps the default. vx: voxels per lane along x (1, 2, 4; capped by

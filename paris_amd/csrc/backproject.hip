@@ -532,6 +532,19 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
 
     const size_t ev = static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size());
     PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
+    if(ctx->bp_variant == 4 && !f16) // the fused kernel with a single projection (measurement: all slices of a tile in flight)
+    {
+        FusedParams fp;
+        fp.g = g;
+        fp.n_proj = 1;
+        fp.proj_stride = 0;
+        fp.sin_phi[0] = sin_phi;
+        fp.cos_phi[0] = cos_phi;
+        const int width = lane_width(d_v, v_dim_x);
+        const int vx = ctx->bp_vx == 4 && width == 4 ? 4 : (ctx->bp_vx == 1 || width < 2 ? 1 : 2);
+        paris_hip_bp_launch_fused(&fp, vx, ctx->bp_tz == 8u ? 8 : 16, ctx->bp_nt != 0, fd, ctx->stream);
+    }
+    else
     if(ctx->bp_variant == 1)
     {
         const dim3 grid((v_dim_x + 255u) / 256u, v_dim_y, v_dim_z);

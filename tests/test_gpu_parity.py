@@ -198,7 +198,7 @@ def assert_bit_equal(got, want):
             len(bad), got.size, x, y, z, got[z, y, x], want[z, y, x]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_backproject_kat_full_bit_exact(be, oracle, kat_golden, variant):
     det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
     vg = B.calculate_volume_geometry(det)
