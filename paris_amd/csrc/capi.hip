@@ -159,6 +159,10 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
         (void)hipFree(kv.second.d_twiddle);
     if(ctx->d_sincos != nullptr)
         (void)hipFree(ctx->d_sincos);
+    for(auto& kv : ctx->proj_pool)
+        (void)hipFree(kv.second);
+    for(auto& kv : ctx->host_pool)
+        (void)hipHostFree(kv.second);
     ctx->defer_count = 0; // projections still deferred are dropped: their volume may be gone (flush or synchronize first)
     if(ctx->defer_ring != nullptr)
         (void)hipFree(ctx->defer_ring);
@@ -269,8 +273,17 @@ extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, u
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     // rows padded to 256 B: every row starts on a cache-line pair and float4 staging stays aligned
     const size_t row = (static_cast<size_t>(dim_x) * sizeof(float) + 255u) & ~static_cast<size_t>(255u);
+    const size_t bytes = row * dim_y;
     void* p = nullptr;
-    PARIS_HIP_TRY(hipMalloc(&p, row * dim_y));
+    auto pooled = ctx->proj_pool.find(bytes);
+    if(pooled != ctx->proj_pool.end())
+    {
+        p = pooled->second;
+        ctx->proj_pool.erase(pooled);
+    }
+    else
+        PARIS_HIP_TRY(hipMalloc(&p, bytes));
+    ctx->proj_allocs[p] = bytes;
     *d_ptr = static_cast<float*>(p);
     *pitch = row;
     return PARIS_HIP_SUCCESS;
@@ -311,12 +324,39 @@ extern "C" int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint3
 
 extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
 {
-    if(int rc = paris_hip_flush_deferred(ctx))
-        return rc;
     if(int rc = paris_hip_bind(ctx))
         return rc;
     if(d_ptr == nullptr)
         return PARIS_HIP_SUCCESS;
+    auto proj = ctx->proj_allocs.find(d_ptr);
+    if(proj != ctx->proj_allocs.end())
+    {
+        // a projection buffer: deferred backprojections hold their own snapshots, nothing pending refers to it
+        const size_t bytes = proj->second;
+        ctx->proj_allocs.erase(proj);
+        PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream)); // whatever was enqueued on it has run before it is handed out again
+        if(ctx->upload_stream != nullptr)
+            PARIS_HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+        if(ctx->proj_pool.size() < paris_hip_ctx::POOL_MAX)
+        {
+            ctx->proj_pool.emplace(bytes, d_ptr);
+            return PARIS_HIP_SUCCESS;
+        }
+        PARIS_HIP_TRY(hipFree(d_ptr));
+        return PARIS_HIP_SUCCESS;
+    }
+    if(ctx->defer_count != 0)
+    {
+        // pending projections write into key_v: run them first if that volume lives in the allocation being freed
+        void* base = nullptr;
+        size_t size = 0;
+        const bool known = hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, d_ptr) == hipSuccess;
+        const char* kv = reinterpret_cast<const char*>(ctx->key_v);
+        if(!known || (kv >= static_cast<const char*>(base) && kv < static_cast<const char*>(base) + size))
+            if(int rc = paris_hip_flush_deferred(ctx))
+                return rc;
+        (void)hipGetLastError();
+    }
     PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
     PARIS_HIP_TRY(hipFree(d_ptr));
     return PARIS_HIP_SUCCESS;
@@ -328,7 +368,16 @@ extern "C" int paris_hip_malloc_host(paris_hip_ctx* ctx, size_t bytes, void** h_
         return rc;
     if(h_ptr == nullptr || bytes == 0)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    PARIS_HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+    auto pooled = ctx->host_pool.find(bytes);
+    if(pooled != ctx->host_pool.end())
+    {
+        *h_ptr = pooled->second;
+        ctx->host_pool.erase(pooled);
+    }
+    else
+        PARIS_HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+    if(bytes <= paris_hip_ctx::POOL_HOST_BYTES)
+        ctx->host_allocs[*h_ptr] = bytes;
     return PARIS_HIP_SUCCESS;
 }
 
@@ -339,6 +388,17 @@ extern "C" int paris_hip_free_host(paris_hip_ctx* ctx, void* h_ptr)
     if(h_ptr == nullptr)
         return PARIS_HIP_SUCCESS;
     PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    auto live = ctx->host_allocs.find(h_ptr);
+    if(live != ctx->host_allocs.end())
+    {
+        const size_t bytes = live->second;
+        ctx->host_allocs.erase(live);
+        if(ctx->host_pool.size() < paris_hip_ctx::POOL_MAX)
+        {
+            ctx->host_pool.emplace(bytes, h_ptr);
+            return PARIS_HIP_SUCCESS;
+        }
+    }
     PARIS_HIP_TRY(hipHostFree(h_ptr));
     return PARIS_HIP_SUCCESS;
 }

@@ -59,6 +59,15 @@ struct paris_hip_ctx
     float* stage_k = nullptr;
     uint32_t stage_k_size = 0;
     float stage_k_tau = 0.f;
+    // Projection-sized buffers are recycled instead of returned to the runtime (the reference's CUDA backend pools its device
+    // projection buffers too, src/cuda/memory.cpp:42-44): PARIS allocates and frees one host and one device buffer per
+    // projection (src/loader.cpp:28-33), and hipMalloc / hipFree / hipHostMalloc cost more than the kernels of a small frame.
+    std::map<void*, size_t> proj_allocs;       // live buffers of paris_hip_malloc_projection -> bytes
+    std::multimap<size_t, void*> proj_pool;    // released ones, by size (at most POOL_MAX)
+    std::map<void*, size_t> host_allocs;       // live pinned buffers of paris_hip_malloc_host up to POOL_HOST_BYTES -> bytes
+    std::multimap<size_t, void*> host_pool;
+    static constexpr size_t POOL_MAX = 8;
+    static constexpr size_t POOL_HOST_BYTES = size_t{256} << 20;
     // deferred backprojection (paris_hip_set_backproject_deferral): projections copied at call time into a device ring and
     // added by one fused launch per `defer_depth` calls; the key_* fields are the arguments the pending calls share
     uint32_t defer_depth = 1; // 1 = immediate

@@ -6,6 +6,7 @@
 //                       [--slabs N] [--roi x1 x2 y1 y2 z1 z2] [--vol dx dy dz l_vx]
 // in.raw holds n_proj frames of n_col x n_row float32; "lcg" generates the SURVEY.md 8c noise frames.
 // out.raw receives the whole (ROI) volume, slabs written at their slice offsets (fixing SURVEY.md Q4).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -112,11 +113,13 @@ int main(int argc, char** argv)
         if(out == nullptr)
             throw paris::stage_runtime_error{"cannot open " + out_path};
 
+        double loop_s = 0.0; // the per-projection loops only (volume allocation, read-back and file output are not the hot path)
         for(int id = 0; id < info.num; ++id) // one task per slab: src/task.cpp:38-48, src/main.cpp:89-108
         {
             const bool last = (info.num - id) <= 1;
             auto v = paris::make_volume(info.geo, last);
             const auto offset = static_cast<std::uint32_t>(id) * info.geo.dim_z;
+            const auto t_start = std::chrono::steady_clock::now();
             for(std::uint32_t i = 0; i < n_proj; ++i)
             {
                 auto p = paris::backend::make_projection_host(det.n_row, det.n_col);
@@ -127,6 +130,7 @@ int main(int argc, char** argv)
                 if(do_filter) paris::filter(d_p, det);
                 paris::backproject(d_p, v, offset, det, vol_geo, false, enable_roi, roi);
             }
+            loop_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
             auto h_v = paris::backend::make_volume_host(v.dim_x, v.dim_y, v.dim_z);
             paris::backend::copy_d2h(v, h_v);
             const auto n = std::size_t{v.dim_x} * v.dim_y * v.dim_z;
@@ -136,6 +140,9 @@ int main(int argc, char** argv)
         }
         std::fclose(out);
         std::printf("ok %u %u %u\n", roi_geo.dim_x, roi_geo.dim_y, roi_geo.dim_z);
+        // calls are synchronous; with deferral the projections still pending after the loop (n_proj modulo the depth) run at read-back
+        std::printf("projection loops %.3f s: %.1f GVoxel-updates/s through paris::load / weight / filter / backproject (deferral depth %d)\n", loop_s,
+                    static_cast<double>(roi_geo.dim_x) * roi_geo.dim_y * roi_geo.dim_z * n_proj / loop_s / 1e9, PARIS_HIP_BACKPROJECT_DEFERRAL);
         return 0;
     }
     catch(const paris::stage_construction_error& e)
