@@ -160,9 +160,15 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
     if(ctx->d_sincos != nullptr)
         (void)hipFree(ctx->d_sincos);
     for(auto& kv : ctx->proj_pool)
-        (void)hipFree(kv.second);
+    {
+        (void)hipEventDestroy(kv.second.released);
+        (void)hipFree(kv.second.ptr);
+    }
     for(auto& kv : ctx->host_pool)
-        (void)hipHostFree(kv.second);
+    {
+        (void)hipEventDestroy(kv.second.released);
+        (void)hipHostFree(kv.second.ptr);
+    }
     ctx->defer_count = 0; // projections still deferred are dropped: their volume may be gone (flush or synchronize first)
     if(ctx->defer_ring != nullptr)
         (void)hipFree(ctx->defer_ring);
@@ -264,6 +270,56 @@ extern "C" int paris_hip_fence_destroy(paris_hip_ctx* ctx, paris_hip_fence* fenc
 
 // ---- memory ------------------------------------------------------------------------------------------
 
+namespace
+{
+    // takes the oldest released buffer of `bytes` if it is free to use (or if the pool is full: then waits for it)
+    int pool_take(std::multimap<size_t, paris_hip_ctx::pooled_buffer>& pool, size_t bytes, void** out)
+    {
+        *out = nullptr;
+        auto it = pool.lower_bound(bytes);
+        if(it == pool.end() || it->first != bytes)
+            return PARIS_HIP_SUCCESS;
+        const hipError_t state = hipEventQuery(it->second.released);
+        if(state == hipErrorNotReady)
+        {
+            if(pool.size() < paris_hip_ctx::POOL_MAX)
+            {
+                (void)hipGetLastError();
+                return PARIS_HIP_SUCCESS; // let the caller allocate another one; the rotation grows up to POOL_MAX
+            }
+            PARIS_HIP_TRY(hipEventSynchronize(it->second.released));
+        }
+        else
+            PARIS_HIP_TRY(state);
+        (void)hipEventDestroy(it->second.released);
+        *out = it->second.ptr;
+        pool.erase(it);
+        return PARIS_HIP_SUCCESS;
+    }
+
+    // parks a buffer with an event marking everything enqueued on the ctx streams so far; false when the pool is full
+    int pool_park(paris_hip_ctx* ctx, std::multimap<size_t, paris_hip_ctx::pooled_buffer>& pool, size_t bytes, void* ptr, bool* parked)
+    {
+        *parked = false;
+        if(pool.size() >= paris_hip_ctx::POOL_MAX)
+            return PARIS_HIP_SUCCESS;
+        if(ctx->upload_stream != nullptr) // uploads into the buffer happen on the other stream: order the compute stream behind them
+        {
+            hipEvent_t up = nullptr;
+            PARIS_HIP_TRY(hipEventCreateWithFlags(&up, hipEventDisableTiming));
+            PARIS_HIP_TRY(hipEventRecord(up, ctx->upload_stream));
+            PARIS_HIP_TRY(hipStreamWaitEvent(ctx->stream, up, 0));
+            (void)hipEventDestroy(up);
+        }
+        hipEvent_t e = nullptr;
+        PARIS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        PARIS_HIP_TRY(hipEventRecord(e, ctx->stream));
+        pool.emplace(bytes, paris_hip_ctx::pooled_buffer{ptr, e});
+        *parked = true;
+        return PARIS_HIP_SUCCESS;
+    }
+}
+
 extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, float** d_ptr,
                                            size_t* pitch)
 {
@@ -275,13 +331,9 @@ extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, u
     const size_t row = (static_cast<size_t>(dim_x) * sizeof(float) + 255u) & ~static_cast<size_t>(255u);
     const size_t bytes = row * dim_y;
     void* p = nullptr;
-    auto pooled = ctx->proj_pool.find(bytes);
-    if(pooled != ctx->proj_pool.end())
-    {
-        p = pooled->second;
-        ctx->proj_pool.erase(pooled);
-    }
-    else
+    if(int rc = pool_take(ctx->proj_pool, bytes, &p))
+        return rc;
+    if(p == nullptr)
         PARIS_HIP_TRY(hipMalloc(&p, bytes));
     ctx->proj_allocs[p] = bytes;
     *d_ptr = static_cast<float*>(p);
@@ -334,14 +386,14 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
         // a projection buffer: deferred backprojections hold their own snapshots, nothing pending refers to it
         const size_t bytes = proj->second;
         ctx->proj_allocs.erase(proj);
-        PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream)); // whatever was enqueued on it has run before it is handed out again
+        bool parked = false;
+        if(int rc = pool_park(ctx, ctx->proj_pool, bytes, d_ptr, &parked))
+            return rc;
+        if(parked)
+            return PARIS_HIP_SUCCESS;
+        PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
         if(ctx->upload_stream != nullptr)
             PARIS_HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
-        if(ctx->proj_pool.size() < paris_hip_ctx::POOL_MAX)
-        {
-            ctx->proj_pool.emplace(bytes, d_ptr);
-            return PARIS_HIP_SUCCESS;
-        }
         PARIS_HIP_TRY(hipFree(d_ptr));
         return PARIS_HIP_SUCCESS;
     }
@@ -368,13 +420,9 @@ extern "C" int paris_hip_malloc_host(paris_hip_ctx* ctx, size_t bytes, void** h_
         return rc;
     if(h_ptr == nullptr || bytes == 0)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    auto pooled = ctx->host_pool.find(bytes);
-    if(pooled != ctx->host_pool.end())
-    {
-        *h_ptr = pooled->second;
-        ctx->host_pool.erase(pooled);
-    }
-    else
+    if(int rc = pool_take(ctx->host_pool, bytes, h_ptr))
+        return rc;
+    if(*h_ptr == nullptr)
         PARIS_HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
     if(bytes <= paris_hip_ctx::POOL_HOST_BYTES)
         ctx->host_allocs[*h_ptr] = bytes;
@@ -387,18 +435,20 @@ extern "C" int paris_hip_free_host(paris_hip_ctx* ctx, void* h_ptr)
         return rc;
     if(h_ptr == nullptr)
         return PARIS_HIP_SUCCESS;
-    PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
     auto live = ctx->host_allocs.find(h_ptr);
     if(live != ctx->host_allocs.end())
     {
         const size_t bytes = live->second;
         ctx->host_allocs.erase(live);
-        if(ctx->host_pool.size() < paris_hip_ctx::POOL_MAX)
-        {
-            ctx->host_pool.emplace(bytes, h_ptr);
+        bool parked = false;
+        if(int rc = pool_park(ctx, ctx->host_pool, bytes, h_ptr, &parked)) // copies from it may still be in flight: the event covers them
+            return rc;
+        if(parked)
             return PARIS_HIP_SUCCESS;
-        }
     }
+    PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if(ctx->upload_stream != nullptr)
+        PARIS_HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
     PARIS_HIP_TRY(hipHostFree(h_ptr));
     return PARIS_HIP_SUCCESS;
 }

@@ -62,12 +62,21 @@ struct paris_hip_ctx
     // Projection-sized buffers are recycled instead of returned to the runtime (the reference's CUDA backend pools its device
     // projection buffers too, src/cuda/memory.cpp:42-44): PARIS allocates and frees one host and one device buffer per
     // projection (src/loader.cpp:28-33), and hipMalloc / hipFree / hipHostMalloc cost more than the kernels of a small frame.
-    std::map<void*, size_t> proj_allocs;       // live buffers of paris_hip_malloc_projection -> bytes
-    std::multimap<size_t, void*> proj_pool;    // released ones, by size (at most POOL_MAX)
-    std::map<void*, size_t> host_allocs;       // live pinned buffers of paris_hip_malloc_host up to POOL_HOST_BYTES -> bytes
-    std::multimap<size_t, void*> host_pool;
+    // A released buffer carries an event recorded on the ctx stream at release time; it is handed out again only after that
+    // event has completed, so the new owner may touch it from the host or from any stream. While the oldest released buffer
+    // is still busy and fewer than POOL_MAX are parked, a fresh one is allocated instead of waiting: an asynchronous caller
+    // ends up rotating through a few buffers and never stalls.
+    struct pooled_buffer
+    {
+        void* ptr;
+        hipEvent_t released;
+    };
+    std::map<void*, size_t> proj_allocs;               // live buffers of paris_hip_malloc_projection -> bytes
+    std::multimap<size_t, pooled_buffer> proj_pool;    // released ones, by size, oldest first (at most POOL_MAX)
+    std::map<void*, size_t> host_allocs;               // live pinned buffers of paris_hip_malloc_host up to POOL_HOST_BYTES -> bytes
+    std::multimap<size_t, pooled_buffer> host_pool;
     static constexpr size_t POOL_MAX = 8;
-    static constexpr size_t POOL_HOST_BYTES = size_t{256} << 20;
+    static constexpr size_t POOL_HOST_BYTES = size_t{64} << 20; // a 4096 x 4096 frame
     // deferred backprojection (paris_hip_set_backproject_deferral): projections copied at call time into a device ring and
     // added by one fused launch per `defer_depth` calls; the key_* fields are the arguments the pending calls share
     uint32_t defer_depth = 1; // 1 = immediate

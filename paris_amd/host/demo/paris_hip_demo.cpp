@@ -130,6 +130,7 @@ int main(int argc, char** argv)
                 if(do_filter) paris::filter(d_p, det);
                 paris::backproject(d_p, v, offset, det, vol_geo, false, enable_roi, roi);
             }
+            paris::backend::synchronize(); // the timed region ends when the GPU has finished, not when the last call returned
             loop_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
             auto h_v = paris::backend::make_volume_host(v.dim_x, v.dim_y, v.dim_z);
             paris::backend::copy_d2h(v, h_v);
@@ -140,7 +141,6 @@ int main(int argc, char** argv)
         }
         std::fclose(out);
         std::printf("ok %u %u %u\n", roi_geo.dim_x, roi_geo.dim_y, roi_geo.dim_z);
-        // calls are synchronous; with deferral the projections still pending after the loop (n_proj modulo the depth) run at read-back
         std::printf("projection loops %.3f s: %.1f GVoxel-updates/s through paris::load / weight / filter / backproject (deferral depth %d)\n", loop_s,
                     static_cast<double>(roi_geo.dim_x) * roi_geo.dim_y * roi_geo.dim_z * n_proj / loop_s / 1e9, PARIS_HIP_BACKPROJECT_DEFERRAL);
         return 0;

@@ -8,14 +8,22 @@
 //
 // Per-device state: the reference binds a host thread to a device with set_device() and keeps everything else
 // in thread_local statics. Here set_device() creates (once per thread and device) the paris_hip_ctx that holds
-// that state; every other function uses the calling thread's current ctx. Calls are synchronous, like the
-// reference's. A non-zero C status becomes stage_runtime_error (stage_construction_error for allocation and
+// that state; every other function uses the calling thread's current ctx. Calls enqueue on the ctx's stream and only
+// the copies to the host wait (PARIS_HIP_SYNCHRONOUS_CALLS=1 restores the reference's sync-per-call). A non-zero C status becomes stage_runtime_error (stage_construction_error for allocation and
 // subvolume planning), after which the reference's main() aborts (src/main.cpp:181-192).
 #ifndef PARIS_AMD_HOST_HIP_BACKEND_H_
 #define PARIS_AMD_HOST_HIP_BACKEND_H_
 
 #ifndef PARIS_HIP_BACKPROJECT_DEFERRAL
 #define PARIS_HIP_BACKPROJECT_DEFERRAL 16
+#endif
+// 1: every backend call returns after its work has finished, like the reference's backends (stream sync before return:
+// src/cuda/weighting.cu:72, filtering.cu:260, backprojection.cu:236). 0 (default): calls enqueue and return; only the
+// copies to the host wait. The call sequence of src/main.cpp:98-105 observes results through copy_d2h alone, and the
+// library hands a released host / device projection buffer out again only after the work that used it has finished, so
+// the loop's allocate / fill / load / free per projection stays correct while host and GPU work overlap.
+#ifndef PARIS_HIP_SYNCHRONOUS_CALLS
+#define PARIS_HIP_SYNCHRONOUS_CALLS 0
 #endif
 
 #include <cstddef>
@@ -105,7 +113,8 @@ namespace paris
             if(it == s.per_device.end())
             {
                 paris_hip_ctx* c = nullptr;
-                detail::construction_check(paris_hip_ctx_create(d, nullptr, PARIS_HIP_CTX_SYNCHRONOUS, &c), "set_device()");
+                detail::construction_check(paris_hip_ctx_create(d, nullptr, PARIS_HIP_SYNCHRONOUS_CALLS ? PARIS_HIP_CTX_SYNCHRONOUS : PARIS_HIP_CTX_DEFAULT, &c),
+                                           "set_device()");
                 // PARIS calls backproject() once per projection (src/main.cpp:98-105). The library snapshots each call's
                 // projection and adds PARIS_HIP_BACKPROJECT_DEFERRAL of them with one fused launch -- bit-identical, the
                 // slab is read and written once per group instead of once per projection -- and flushes before anything
@@ -210,6 +219,7 @@ namespace paris
             detail::runtime_check(paris_hip_memcpy_projection_d2h(current_ctx(), h_p.buf.get(), std::size_t{h_p.dim_x} * sizeof(float),
                                                                   d_p.buf.get(), d_p.buf.pitch(), d_p.dim_x, d_p.dim_y),
                                   "copy_d2h(projection)");
+            detail::runtime_check(paris_hip_ctx_synchronize(current_ctx()), "copy_d2h(projection)"); // the host reads h_p next
             h_p.idx = d_p.idx;
             h_p.phi = d_p.phi;
             h_p.meta = d_p.meta;
@@ -226,7 +236,14 @@ namespace paris
         {
             detail::runtime_check(paris_hip_memcpy_volume_d2h(current_ctx(), h_v.buf.get(), d_v.buf.get(), d_v.dim_x, d_v.dim_y, d_v.dim_z),
                                   "copy_d2h(volume)");
+            detail::runtime_check(paris_hip_ctx_synchronize(current_ctx()), "copy_d2h(volume)"); // the host reads h_v next
             h_v.off = d_v.off;
+        }
+
+        // Extension (no reference counterpart): runs what is deferred and waits for everything enqueued on this thread's device.
+        inline auto synchronize() -> void
+        {
+            detail::runtime_check(paris_hip_ctx_synchronize(current_ctx()), "synchronize()");
         }
 
         // ---- subvolume planning (src/cuda/subvolume_information.cpp:63-118) ---------------------------------------
