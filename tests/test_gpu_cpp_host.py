@@ -13,11 +13,11 @@ DEMO = os.path.join(ROOT, "paris_amd", "host", "demo", "paris_hip_demo")
 KAT_ARGS = ["64", "48", "0.2", "0.25", "1.5", "-0.75", "100", "200", "45", "8"]
 
 
-def run_demo(tmp_path, in_spec, extra):
+def run_demo(tmp_path, in_spec, extra, exe=DEMO):
     out = tmp_path / "vol.raw"
-    if not os.path.exists(DEMO):
-        pytest.fail("%s missing: run __graft_entry__.build()" % DEMO)
-    r = subprocess.run([DEMO] + KAT_ARGS + [in_spec, str(out)] + extra, capture_output=True, text=True, timeout=120)
+    if not os.path.exists(exe):
+        pytest.fail("%s missing: run __graft_entry__.build()" % exe)
+    r = subprocess.run([exe] + KAT_ARGS + [in_spec, str(out)] + extra, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     dims = [int(x) for x in r.stdout.split()[1:4]]
     return np.fromfile(out, np.float32).reshape(dims[2], dims[1], dims[0])
@@ -41,6 +41,15 @@ def test_cpp_loop_backprojection_bit_exact(tmp_path, gold, extra, crop):
     want = gold["volume"][crop]
     assert got.shape == want.shape
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_cpp_loop_one_launch_per_call(tmp_path, gold):
+    """The same loop built with PARIS_HIP_BACKPROJECT_DEFERRAL=1 (paris_hip_demo_immediate): asynchronous calls, recycled
+    buffers, one backprojection launch per projection."""
+    f = tmp_path / "filtered.raw"
+    gold["filtered"].astype(np.float32).tofile(f)
+    got = run_demo(tmp_path, str(f), ["--no-weight", "--no-filter", "--slabs", "3"], DEMO + "_immediate")
+    assert np.array_equal(got.view(np.uint32), gold["volume"].view(np.uint32))
 
 
 def test_cpp_loop_full_pipeline(tmp_path, gold):
