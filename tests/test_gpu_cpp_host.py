@@ -52,6 +52,32 @@ def test_cpp_loop_one_launch_per_call(tmp_path, gold):
     assert np.array_equal(got.view(np.uint32), gold["volume"].view(np.uint32))
 
 
+@pytest.mark.parametrize("exe", [DEMO, DEMO + "_immediate"])
+def test_cpp_loop_many_projections_rotating_buffers(tmp_path, oracle, exe):
+    """40 projections of 200 x 160 through the asynchronous loop: the deferral ring fills and flushes twice (16 + 16 + 8 at
+    read-back), released host / device projection buffers rotate through the library's pools while earlier uploads and
+    launches are still in flight. Bit-identical to the oracle's backprojection of the same frames."""
+    n_row, n_col, n_proj = 200, 160, 40
+    args = [str(n_row), str(n_col), "0.2", "0.2", "0.5", "-0.25", "300", "200", "9", str(n_proj)]
+    frames = np.stack([oracle.lcg_projection(n_row, n_col, i) - np.float32(0.5) for i in range(n_proj)])
+    f = tmp_path / "in.raw"
+    frames.tofile(f)
+    out = tmp_path / "vol.raw"
+    r = subprocess.run([exe] + args + [str(f), str(out), "--no-weight", "--no-filter", "--slabs", "2"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    dims = [int(x) for x in r.stdout.split()[1:4]]
+    got = np.fromfile(out, np.float32).reshape(dims[2], dims[1], dims[0])
+    det = oracle.DetectorGeometry(n_row, n_col, 0.2, 0.2, 0.5, -0.25, 300, 200, 9)
+    vg = oracle.calculate_volume_geometry(det)
+    assert (vg.dim_x, vg.dim_y, vg.dim_z) == tuple(dims)
+    want = np.zeros((vg.dim_z, vg.dim_y, vg.dim_x), np.float32)
+    for i in range(n_proj):
+        s, c, ds, dt = oracle.backproject_constants(det, i)
+        oracle.backproject(want, frames[i], 0, det, vg, s, c, ds, dt)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_cpp_loop_full_pipeline(tmp_path, gold):
     got = run_demo(tmp_path, "lcg", ["--slabs", "2"])
     want = gold["volume"]
