@@ -160,6 +160,13 @@ int paris_hip_weight_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t
  * product is identical) owned by the caller: release with paris_hip_free. size must be a
  * power of two in [8, 16384]. */
 int paris_hip_make_filter(paris_hip_ctx* ctx, uint32_t size, float tau, float** d_k);
+/* Extension: the same K multiplied by a window. The reference implements the ramp only;
+ * PARIS_HIP_WINDOW_SHEPP_LOGAN multiplies bin f by sinc(pi f / size) (1 at DC, 2/pi at Nyquist). */
+#define PARIS_HIP_WINDOW_RAMP 0
+#define PARIS_HIP_WINDOW_SHEPP_LOGAN 1
+int paris_hip_make_filter_windowed(paris_hip_ctx* ctx, uint32_t size, float tau, int window, float** d_k);
+/* Selects the window of the K that paris_hip_stage_filter builds and caches (default: the reference's ramp). */
+int paris_hip_set_filter_window(paris_hip_ctx* ctx, int window);
 /* In place, per detector row: zero-pad to filter_size, FFT, multiply by K, inverse FFT, keep the first dim_x
  * samples, divide by filter_size. n_col is the number of rows (== dim_y; kept because the reference passes
  * it, src/filtering.cpp:44). */

@@ -81,6 +81,8 @@ SIGNATURES = {
     "paris_hip_weight": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _f, _f, _f, _f, _f]),
     "paris_hip_weight_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _f, _f, _f, _f, _f]),
     "paris_hip_make_filter": (C.c_int, [_vp, _u32, _f, _P(_vp)]),
+    "paris_hip_make_filter_windowed": (C.c_int, [_vp, _u32, _f, C.c_int, _P(_vp)]),
+    "paris_hip_set_filter_window": (C.c_int, [_vp, C.c_int]),
     "paris_hip_apply_filter": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _u32, _u32]),
     "paris_hip_set_filter_variant": (C.c_int, [_vp, C.c_int]),
     "paris_hip_backproject": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _u32, _u32, _u32, _u32,

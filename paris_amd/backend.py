@@ -190,10 +190,10 @@ class Backend:
         check(self._L.paris_hip_weight(self._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, h_min, v_min, d_sd,
                                        l_px_row, l_px_col), "paris_hip_weight")
 
-    def make_filter(self, size, tau):
-        """backend::make_filter (src/openmp/filtering.cpp:139-165)"""
+    def make_filter(self, size, tau, window=0):
+        """backend::make_filter (src/openmp/filtering.cpp:139-165); window 1 = Shepp-Logan (extension)"""
         ptr = C.c_void_p()
-        check(self._L.paris_hip_make_filter(self._ctx, size, tau, C.byref(ptr)), "paris_hip_make_filter")
+        check(self._L.paris_hip_make_filter_windowed(self._ctx, size, tau, window, C.byref(ptr)), "paris_hip_make_filter")
         self._owned.add(ptr.value)
         return FilterBuffer(ptr.value, size, self)
 
@@ -290,6 +290,10 @@ class Backend:
     def set_backproject_slice_shape(self, waves=0, row_groups=0):
         check(self._L.paris_hip_set_backproject_slice_shape(self._ctx, waves, row_groups),
               "paris_hip_set_backproject_slice_shape")
+
+    def set_filter_window(self, window):
+        """window of the K that the filter stage wrapper builds: 0 = the reference's ramp, 1 = Shepp-Logan"""
+        check(self._L.paris_hip_set_filter_window(self._ctx, window), "paris_hip_set_filter_window")
 
     def set_backproject_deferral(self, depth):
         """depth > 1: backproject() calls are snapshotted and added by one fused launch per `depth` calls (bit-identical)"""

@@ -85,7 +85,7 @@ namespace
     }
 
     // src/openmp/filtering.cpp:52-73 + :139-165 -- one workgroup
-    __global__ void make_filter_kernel(float* __restrict__ k, const float2* __restrict__ tw, uint32_t log2n, float tau)
+    __global__ void make_filter_kernel(float* __restrict__ k, const float2* __restrict__ tw, uint32_t log2n, float tau, int window)
     {
         extern __shared__ __attribute__((aligned(16))) float2 fx[];
         const uint32_t n = 1u << log2n;
@@ -113,7 +113,15 @@ namespace
             if(f <= n / 2)
             {
                 const float2 v = fx[p];
-                k[f] = tau * fabsf(sqrtf(v.x * v.x + v.y * v.y)); // :157
+                float kf = tau * fabsf(sqrtf(v.x * v.x + v.y * v.y)); // :157
+                if(window == PARIS_HIP_WINDOW_SHEPP_LOGAN && f != 0u)
+                {
+                    // extension (the reference implements the ramp only): Shepp-Logan window
+                    // sinc(pi f / N): 1 at DC, 2/pi at the Nyquist bin f = N/2
+                    const float x = pi_f * static_cast<float>(f) / static_cast<float>(n);
+                    kf *= sinf(x) / x;
+                }
+                k[f] = kf;
             }
         }
     }
@@ -464,9 +472,15 @@ int paris_hip_get_plan(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_plan** out)
 
 extern "C" int paris_hip_make_filter(paris_hip_ctx* ctx, uint32_t size, float tau, float** d_k)
 {
+    return paris_hip_make_filter_windowed(ctx, size, tau, PARIS_HIP_WINDOW_RAMP, d_k);
+}
+
+extern "C" int paris_hip_make_filter_windowed(paris_hip_ctx* ctx, uint32_t size, float tau, int window, float** d_k)
+{
     if(int rc = paris_hip_bind(ctx))
         return rc;
-    if(d_k == nullptr || !is_pow2(size) || size < MIN_N || size > MAX_N)
+    if(d_k == nullptr || !is_pow2(size) || size < MIN_N || size > MAX_N
+       || (window != PARIS_HIP_WINDOW_RAMP && window != PARIS_HIP_WINDOW_SHEPP_LOGAN))
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(int rc = ensure_lds_limit(ctx))
         return rc;
@@ -476,7 +490,7 @@ extern "C" int paris_hip_make_filter(paris_hip_ctx* ctx, uint32_t size, float ta
     float* k = nullptr;
     PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&k), (size / 2 + 1) * sizeof(float)));
     hipLaunchKernelGGL(make_filter_kernel, dim3(1), dim3(threads_for(size)), size * sizeof(float2), ctx->stream, k,
-                       plan->d_twiddle, ilog2(size), tau);
+                       plan->d_twiddle, ilog2(size), tau, window);
     *d_k = k;
     return paris_hip_finish(ctx);
 }

@@ -59,6 +59,7 @@ struct paris_hip_ctx
     float* stage_k = nullptr;
     uint32_t stage_k_size = 0;
     float stage_k_tau = 0.f;
+    int stage_window = 0, stage_k_window = 0; // requested window / window of the cached K
     // Projection-sized buffers are recycled instead of returned to the runtime (the reference's CUDA backend pools its device
     // projection buffers too, src/cuda/memory.cpp:42-44): PARIS allocates and frees one host and one device buffer per
     // projection (src/loader.cpp:28-33), and hipMalloc / hipFree / hipHostMalloc cost more than the kernels of a small frame.

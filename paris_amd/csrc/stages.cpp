@@ -107,7 +107,7 @@ extern "C" int paris_hip_stage_filter_rows(paris_hip_ctx* ctx, float* d_p, size_
     // thread_local static (:42)
     const uint32_t filter_size = paris_hip_filter_size(det_geo->n_row);
     const float tau = det_geo->l_px_row;
-    if(ctx->stage_k == nullptr || ctx->stage_k_size != filter_size || ctx->stage_k_tau != tau)
+    if(ctx->stage_k == nullptr || ctx->stage_k_size != filter_size || ctx->stage_k_tau != tau || ctx->stage_k_window != ctx->stage_window)
     {
         if(ctx->stage_k != nullptr)
         {
@@ -115,10 +115,11 @@ extern "C" int paris_hip_stage_filter_rows(paris_hip_ctx* ctx, float* d_p, size_
                 return rc;
             ctx->stage_k = nullptr;
         }
-        if(int rc = paris_hip_make_filter(ctx, filter_size, tau, &ctx->stage_k))
+        if(int rc = paris_hip_make_filter_windowed(ctx, filter_size, tau, ctx->stage_window, &ctx->stage_k))
             return rc;
         ctx->stage_k_size = filter_size;
         ctx->stage_k_tau = tau;
+        ctx->stage_k_window = ctx->stage_window;
     }
     float* rows = reinterpret_cast<float*>(reinterpret_cast<char*>(d_p) + static_cast<size_t>(row_first) * pitch);
     return paris_hip_apply_filter(ctx, rows, pitch, dim_x, row_count, ctx->stage_k, filter_size, row_count);
@@ -233,5 +234,13 @@ extern "C" int paris_hip_slab_row_band(const paris_detector_geometry* det_geo, c
     b = std::min(b | 1u, n_col - 1u);
     *row_first = a;
     *row_count = b - a + 1u;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_set_filter_window(paris_hip_ctx* ctx, int window)
+{
+    if(ctx == nullptr || (window != PARIS_HIP_WINDOW_RAMP && window != PARIS_HIP_WINDOW_SHEPP_LOGAN))
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    ctx->stage_window = window; // the cached K is rebuilt by the next paris_hip_stage_filter
     return PARIS_HIP_SUCCESS;
 }

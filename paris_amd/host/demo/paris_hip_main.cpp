@@ -5,6 +5,7 @@
 //   paris.hip --geometry geo.ini --input <dir> --output <dir> [--name vol] [--angles file] [--quality q]
 //             [--roi --roi-x1 a --roi-x2 b --roi-y1 c --roi-y2 d --roi-z1 e --roi-z2 f]
 //             [--slabs n] [--devices n] [--f16] [--no-row-band] [--batch n] [--drain-chunk-kib n]
+//             [--window ramp|shepp-logan]
 // geo.ini: key=value lines for n_row n_col l_px_row l_px_col delta_s delta_t d_so d_od delta_phi (:83-91).
 #include <cstdio>
 #include <cstdlib>
@@ -89,6 +90,13 @@ int main(int argc, char** argv)
             else if(k == "--devices") po.devices = std::stoi(val());
             else if(k == "--f16") po.f16 = true;
             else if(k == "--no-row-band") po.row_band = false;
+            else if(k == "--window")
+            {
+                const auto w = val();
+                if(w == "ramp") po.window = PARIS_HIP_WINDOW_RAMP;
+                else if(w == "shepp-logan") po.window = PARIS_HIP_WINDOW_SHEPP_LOGAN;
+                else throw paris::stage_construction_error{"unknown filter window " + w};
+            }
             else if(k == "--batch") po.batch = std::stoi(val());
             else if(k == "--drain-chunk-kib") po.drain_chunk_bytes = static_cast<std::size_t>(std::stoull(val())) << 10;
             else throw paris::stage_construction_error{"unknown option " + k};

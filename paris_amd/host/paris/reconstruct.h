@@ -50,6 +50,7 @@ namespace paris
         bool f16 = false;  // store filtered projections as IEEE half before backprojection (BASELINE config 5)
         int batch = 16;    // projections per fused backprojection launch (1: one launch per projection, as the reference)
         std::size_t drain_chunk_bytes = std::size_t{256} << 20; // pinned staging per buffer for the volume's way to the file
+        int window = PARIS_HIP_WINDOW_RAMP; // filter window (extension: PARIS_HIP_WINDOW_SHEPP_LOGAN; the reference has the ramp only)
         bool row_band = true; // f4: per slab, upload / weight / filter only the detector rows the slab can read
     };
 
@@ -132,6 +133,7 @@ namespace paris
         // half-precision path) is the reference's one launch per projection with `slots` single-frame groups.
         const std::uint32_t batch = po.f16 || po.batch < 1 ? 1u : static_cast<std::uint32_t>(po.batch > 32 ? 32 : po.batch);
         const std::uint32_t groups = batch == 1u ? static_cast<std::uint32_t>(po.slots < 1 ? 1 : po.slots) : 2u;
+        rt(paris_hip_set_filter_window(ctx, po.window), "filter window");
         const int slots = static_cast<int>(batch * groups);
         const auto n_row = po.det_geo.n_row, n_col = po.det_geo.n_col;
         const auto frame_bytes = static_cast<std::size_t>(n_row) * n_col * sizeof(float);

@@ -105,6 +105,37 @@ def test_make_filter(be, oracle, n, tau):
     be.free(k)
 
 
+@pytest.mark.parametrize("n,tau", [(128, 0.2), (2048, 0.2), (4096, 0.127)])
+def test_shepp_logan_window_extension(be, oracle, n, tau):
+    """Extension (the reference has the ramp only): K_ramp[f] * sinc(pi f / N), against float64."""
+    k_ramp = oracle.make_filter(n, tau).astype(np.float64)
+    f = np.arange(n // 2 + 1, dtype=np.float64)
+    x = np.pi * f / n
+    want = k_ramp * np.where(f == 0, 1.0, np.sin(x) / np.where(f == 0, 1.0, x))
+    k = be.make_filter(n, tau, window=1)
+    got = be.filter_to_host(k)
+    be.free(k)
+    assert np.max(np.abs(got - want)) <= FILTER_TOL * np.abs(want).max()
+    assert abs(got[n // 2] / k_ramp[n // 2] - 2 / np.pi) < 1e-5
+    # the stage wrapper follows the ctx's window and rebuilds its cached K when it changes
+    det = B.DetectorGeometry(64, 48, 0.2, 0.25, 0, 0, 100, 200, 45)
+    p = oracle.lcg_projection(64, 48, 3)
+    outs = []
+    for window in (0, 1, 0):
+        be.set_filter_window(window)
+        d_p = to_device(be, p)
+        B.filter(be, d_p, det)
+        outs.append(to_host(be, d_p))
+        be.free(d_p)
+    assert np.array_equal(outs[0], outs[2]) and not np.array_equal(outs[0], outs[1])
+    ref = p.astype(np.float64)
+    kk = oracle.make_filter(128, 0.2).astype(np.float64)
+    ff = np.arange(65)
+    kk_sl = kk * np.where(ff == 0, 1.0, np.sin(np.pi * ff / 128) / np.where(ff == 0, 1.0, np.pi * ff / 128))
+    want_rows = np.fft.irfft(np.fft.rfft(ref, 128, axis=1) * kk_sl, 128, axis=1)[:, :64]
+    assert np.max(np.abs(outs[1] - want_rows)) <= FILTER_TOL * np.abs(want_rows).max()
+
+
 def test_make_filter_golden(be, kat_golden):
     for n in (128, 1024, 2048, 4096):
         k = be.make_filter(n, 0.2)
