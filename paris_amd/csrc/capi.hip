@@ -155,6 +155,8 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if(ctx->stream != nullptr)
         (void)hipStreamSynchronize(ctx->stream);
+    if(ctx->upload_stream != nullptr)
+        (void)hipStreamSynchronize(ctx->upload_stream);
     for(auto& kv : ctx->plans)
         (void)hipFree(kv.second.d_twiddle);
     if(ctx->d_sincos != nullptr)
@@ -176,7 +178,6 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
         (void)hipFree(ctx->stage_k);
     if(ctx->upload_stream != nullptr)
     {
-        (void)hipStreamSynchronize(ctx->upload_stream);
         for(hipEvent_t e : ctx->upload_events)
             (void)hipEventDestroy(e);
         (void)hipStreamDestroy(ctx->upload_stream);
