@@ -252,9 +252,10 @@ def main():
 
     # ---- extension, outside the headline: the same step with ONE fused launch per batch (paris_hip_backproject_batch)
     fused = None
-    if args.fused_steps > 0 and not f16 and roi is None:
+    if args.fused_steps > 0:
         sc = [B.stage_angle(det, b) for b in range(w["n_proj"])]
         stride = work.stride(0) * 4
+        halves = torch.empty((args.batch, n_col, n_row), device=dev, dtype=torch.float16) if f16 else None
 
         def fused_step(s):
             idx = [(s * args.batch + b) % w["n_proj"] for b in range(args.batch)]
@@ -262,8 +263,15 @@ def main():
                 work[b, band].copy_(raw[b, band], non_blocking=True)
                 B.weight_rows(be, projs[b], det, band_first, band_count)
                 B.filter_rows(be, projs[b], det, band_first, band_count)
-            be.backproject_batch(work.data_ptr(), pitch, stride, args.batch, n_row, n_col, d_vol, z_first, det, vol_geo, False,
-                                 None, [sc[i][0] for i in idx], [sc[i][1] for i in idx], 0.0, 0.0)
+                if f16:
+                    B._lib.check(be._L.paris_hip_convert_projection_f16(be._ctx, projs[b].ptr, pitch, halves[b].data_ptr(), n_row * 2,
+                                                                       n_row, n_col), "paris_hip_convert_projection_f16")
+            if f16:
+                be.backproject_batch_f16(halves.data_ptr(), n_row * 2, n_row * n_col * 2, args.batch, n_row, n_col, d_vol, z_first, det,
+                                         vol_geo, roi is not None, roi, [sc[i][0] for i in idx], [sc[i][1] for i in idx], 0.0, 0.0)
+            else:
+                be.backproject_batch(work.data_ptr(), pitch, stride, args.batch, n_row, n_col, d_vol, z_first, det, vol_geo,
+                                     roi is not None, roi, [sc[i][0] for i in idx], [sc[i][1] for i in idx], 0.0, 0.0)
 
         fused_step(0)
         torch.cuda.synchronize()
@@ -285,7 +293,8 @@ def main():
 
         # ---- the same per-projection calls as the headline, with the library's deferral switched on: every
         # paris_hip_backproject call snapshots its projection, `batch` of them are added by one fused launch
-        be.set_backproject_deferral(args.batch)
+        # (fp32 calls only; the half-precision entry point is not deferred)
+        be.set_backproject_deferral(1 if f16 else args.batch)
         step(0)
         be.flush()
         torch.cuda.synchronize()
@@ -355,18 +364,19 @@ def main():
                 "kernel_ms_per_launch": fused["kernel_ms"],
                 "kernel_GVox_per_s_per_gpu": per_launch / (fused["kernel_ms"] * 1e-3) / 1e9 if fused["kernel_ms"] > 0 else 0.0,
                 "algorithmic_bytes_per_update": 8.0 / args.batch,
-                "hbm_GBps": (8.0 * voxels_rank + 4.0 * n_row * n_col * args.batch) / (fused["kernel_ms"] * 1e-3) / 1e9
+                "hbm_GBps": (8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col * args.batch) / (fused["kernel_ms"] * 1e-3) / 1e9
                             if fused["kernel_ms"] > 0 else 0.0,
                 "bound": "vector ALU issue (HBM term divided by the batch size)",
             }
-            out["deferred_boundary"] = {
-                "what": "the headline's step unchanged -- one paris_hip_backproject call per projection -- with "
-                        "paris_hip_set_backproject_deferral(%d): the library snapshots each call's projection and adds %d of them "
-                        "per fused launch (bit-identical volume); what PARIS's per-projection loop gets through paris::hip"
-                        % (args.batch, args.batch),
-                "value": voxels_all * args.batch * fused["steps"] / fused["deferred_seconds"] / 1e9,
-                "unit": "GVoxel-updates/s",
-            }
+            if not f16:
+                out["deferred_boundary"] = {
+                    "what": "the headline's step unchanged -- one paris_hip_backproject call per projection -- with "
+                            "paris_hip_set_backproject_deferral(%d): the library snapshots each call's projection and adds %d of "
+                            "them per fused launch (bit-identical volume); what PARIS's per-projection loop gets through paris::hip"
+                            % (args.batch, args.batch),
+                    "value": voxels_all * args.batch * fused["steps"] / fused["deferred_seconds"] / 1e9,
+                    "unit": "GVoxel-updates/s",
+                }
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -217,6 +217,14 @@ int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p, size_t p_p
                                 int enable_roi, const paris_region_of_interest* roi, const float* sin_phi,
                                 const float* cos_phi, float delta_s, float delta_t);
 
+/* The same for IEEE-half projections (paris_hip_backproject_f16 semantics; p_pitch / p_stride_bytes in bytes of half rows). */
+int paris_hip_backproject_batch_f16(paris_hip_ctx* ctx, const uint16_t* d_p, size_t p_pitch, size_t p_stride_bytes,
+                                    uint32_t n_proj, uint32_t p_dim_x, uint32_t p_dim_y, float* d_v, uint32_t v_dim_x,
+                                    uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
+                                    const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo,
+                                    int enable_roi, const paris_region_of_interest* roi, const float* sin_phi,
+                                    const float* cos_phi, float delta_s, float delta_t);
+
 /* Extension: deferred backprojection. With depth n > 1 (n <= 64), paris_hip_backproject copies its projection into a ring
  * owned by the ctx (stream-ordered device-to-device copy: the caller may reuse its buffer as after any asynchronous
  * call) and returns; the pending projections are added by ONE fused launch, in call order and bit-identical to n

@@ -95,6 +95,9 @@ SIGNATURES = {
     "paris_hip_backproject_batch": (C.c_int, [_vp, _vp, _sz, _sz, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32,
                                               _P(DetectorGeometry), _P(VolumeGeometry), C.c_int,
                                               _P(RegionOfInterest), _P(_f), _P(_f), _f, _f]),
+    "paris_hip_backproject_batch_f16": (C.c_int, [_vp, _vp, _sz, _sz, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32,
+                                              _P(DetectorGeometry), _P(VolumeGeometry), C.c_int,
+                                              _P(RegionOfInterest), _P(_f), _P(_f), _f, _f]),
     "paris_hip_calculate_volume_geometry": (C.c_int, [_P(DetectorGeometry), _P(VolumeGeometry)]),
     "paris_hip_apply_roi": (C.c_int, [_P(VolumeGeometry), _P(RegionOfInterest), _P(VolumeGeometry)]),
     "paris_hip_stage_weight": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _P(DetectorGeometry)]),

@@ -252,6 +252,16 @@ class Backend:
                                                   C.byref(vol_geo), int(bool(enable_roi)), C.byref(r), s, c,
                                                   delta_s, delta_t), "paris_hip_backproject_batch")
 
+    def backproject_batch_f16(self, p_ptr, p_pitch, p_stride, n_proj, p_dim_x, p_dim_y, v, v_offset, det_geo, vol_geo,
+                              enable_roi, roi, sins, coss, delta_s, delta_t):
+        r = roi if roi is not None else RegionOfInterest()
+        s = (C.c_float * n_proj)(*sins)
+        c = (C.c_float * n_proj)(*coss)
+        check(self._L.paris_hip_backproject_batch_f16(self._ctx, p_ptr, p_pitch, p_stride, n_proj, p_dim_x, p_dim_y,
+                                                      v.ptr, v.dim_x, v.dim_y, v.dim_z, v_offset, C.byref(det_geo),
+                                                      C.byref(vol_geo), int(bool(enable_roi)), C.byref(r), s, c,
+                                                      delta_s, delta_t), "paris_hip_backproject_batch_f16")
+
     # ---- diagnostics ------------------------------------------------------------------------------------------
     def last_backproject_ms(self):
         ms = C.c_float()

@@ -585,7 +585,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
 // copy, so the caller may reuse its buffer as usual) and returns; n pending calls -- or fewer when a call with other
 // volume / geometry arguments arrives or when the volume is observed -- are added by ONE fused launch in call order,
 // which is bit-identical to n single launches and moves 8/n instead of 8 bytes per voxel-update.
-static int batch_impl(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, size_t p_stride_bytes, uint32_t n_proj, uint32_t p_dim_x,
+static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, size_t p_stride_bytes, uint32_t n_proj, uint32_t p_dim_x,
                       uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
                       const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
                       const paris_region_of_interest* roi, const float* sin_phi, const float* cos_phi, float delta_s, float delta_t);
@@ -598,7 +598,7 @@ int paris_hip_flush_deferred(paris_hip_ctx* ctx)
     ctx->defer_count = 0; // first: batch_impl may fall back to single launches, which must not be deferred again
     const uint32_t depth = ctx->defer_depth;
     ctx->defer_depth = 1;
-    const int rc = batch_impl(ctx, ctx->defer_ring, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
+    const int rc = batch_impl(ctx, ctx->defer_ring, false, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
                               ctx->defer_dim_y, ctx->key_v, ctx->key_dims[0], ctx->key_dims[1], ctx->key_dims[2], ctx->key_dims[3],
                               &ctx->key_det, &ctx->key_vol, ctx->key_enable_roi, &ctx->key_roi, ctx->defer_sin.data(),
                               ctx->defer_cos.data(), ctx->key_delta_s, ctx->key_delta_t);
@@ -752,16 +752,30 @@ extern "C" int paris_hip_backproject_batch(paris_hip_ctx* ctx, const float* d_p,
 {
     if(int rc = paris_hip_flush_deferred(ctx)) // keeps the call order of deferred and explicit batches
         return rc;
-    return batch_impl(ctx, d_p, p_pitch, p_stride_bytes, n_proj, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
+    return batch_impl(ctx, d_p, false, p_pitch, p_stride_bytes, n_proj, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
                       vol_geo, enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
 }
 
-static int batch_impl(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, size_t p_stride_bytes, uint32_t n_proj, uint32_t p_dim_x,
+extern "C" int paris_hip_backproject_batch_f16(paris_hip_ctx* ctx, const uint16_t* d_p, size_t p_pitch, size_t p_stride_bytes,
+                                               uint32_t n_proj, uint32_t p_dim_x, uint32_t p_dim_y, float* d_v, uint32_t v_dim_x,
+                                               uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
+                                               const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo,
+                                               int enable_roi, const paris_region_of_interest* roi, const float* sin_phi,
+                                               const float* cos_phi, float delta_s, float delta_t)
+{
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
+    return batch_impl(ctx, d_p, true, p_pitch, p_stride_bytes, n_proj, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
+                      vol_geo, enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
+}
+
+static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, size_t p_stride_bytes, uint32_t n_proj, uint32_t p_dim_x,
                       uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
                       const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
                       const paris_region_of_interest* roi, const float* sin_phi, const float* cos_phi, float delta_s, float delta_t)
 {
-    if(ctx == nullptr || sin_phi == nullptr || cos_phi == nullptr || p_stride_bytes % sizeof(float) != 0)
+    const size_t px = f16 ? sizeof(uint16_t) : sizeof(float);
+    if(ctx == nullptr || sin_phi == nullptr || cos_phi == nullptr || p_stride_bytes % px != 0)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(n_proj == 0)
         return paris_hip_finish(ctx);
@@ -785,9 +799,9 @@ static int batch_impl(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, size
         int rc = PARIS_HIP_SUCCESS;
         for(uint32_t i = 0; i < n_proj && rc == PARIS_HIP_SUCCESS; ++i)
         {
-            const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_p) + i * p_stride_bytes);
-            rc = paris_hip_backproject(ctx, p, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
-                                       enable_roi, roi, sin_phi[i], cos_phi[i], delta_s, delta_t);
+            const char* p = static_cast<const char*>(d_p) + i * p_stride_bytes;
+            rc = backproject_impl(ctx, p, f16, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
+                                  enable_roi, roi, sin_phi[i], cos_phi[i], delta_s, delta_t);
         }
         ctx->flags = saved;
         if(rc != PARIS_HIP_SUCCESS)
@@ -803,13 +817,13 @@ static int batch_impl(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, size
         FusedParams fp;
         bool fd = false, skip = false;
         const char* p0 = reinterpret_cast<const char*>(d_p) + static_cast<size_t>(first) * p_stride_bytes;
-        if(int rc = fill_params(ctx, p0, false, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
+        if(int rc = fill_params(ctx, p0, f16, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
                                 vol_geo, enable_roi, roi, sin_phi[first], cos_phi[first], delta_s, delta_t, fp.g, fd, skip))
             return rc;
         if(skip)
             break;
         fp.n_proj = n;
-        fp.proj_stride = static_cast<uint32_t>(p_stride_bytes / sizeof(float));
+        fp.proj_stride = static_cast<uint32_t>(p_stride_bytes / px);
         for(uint32_t i = 0; i < n; ++i)
         {
             fp.sin_phi[i] = sin_phi[first + i];

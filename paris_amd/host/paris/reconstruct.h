@@ -128,10 +128,10 @@ namespace paris
         rt(paris_hip_ctx_create(device, nullptr, PARIS_HIP_CTX_DEFAULT, &ctx), "set_device()"); // :87
 
         // Projections travel in groups: a group of `batch` frames is converted, uploaded, weighted and filtered one by one,
-        // then backprojected with ONE fused launch (paris_hip_backproject_batch: bit-identical to the sequence, the slab is
-        // read and written once per group). While the GPU works on one group the host fills the next. batch = 1 (and the
-        // half-precision path) is the reference's one launch per projection with `slots` single-frame groups.
-        const std::uint32_t batch = po.f16 || po.batch < 1 ? 1u : static_cast<std::uint32_t>(po.batch > 32 ? 32 : po.batch);
+        // then backprojected with ONE fused launch (paris_hip_backproject_batch[_f16]: bit-identical to the sequence, the slab
+        // is read and written once per group). While the GPU works on one group the host fills the next. batch = 1 is the
+        // reference's one launch per projection with `slots` single-frame groups.
+        const std::uint32_t batch = po.batch < 1 ? 1u : static_cast<std::uint32_t>(po.batch > 32 ? 32 : po.batch);
         const std::uint32_t groups = batch == 1u ? static_cast<std::uint32_t>(po.slots < 1 ? 1 : po.slots) : 2u;
         rt(paris_hip_set_filter_window(ctx, po.window), "filter window");
         const int slots = static_cast<int>(batch * groups);
@@ -141,7 +141,7 @@ namespace paris
         auto d_buf = std::vector<float*>(slots, nullptr);
         auto fence = std::vector<paris_hip_fence*>(groups, nullptr);
         float* d_all = nullptr; // the device frames of all slots, one under the other: slot s starts at row s * n_col
-        std::size_t d_pitch = 0, h16_pitch = 0;
+        std::size_t d_pitch = 0, h16_pitch = 0, h16_stride = 0;
         std::uint16_t* d_half = nullptr;
         float* d_v = nullptr;
         float* h_stage[2] = {nullptr, nullptr}; // pinned staging for the drain: D2H of chunk k+1 overlaps the file write of chunk k
@@ -182,9 +182,12 @@ namespace paris
                 float* raw = nullptr;
                 h16_pitch = (static_cast<std::size_t>(n_row) * 2 + 255) / 256 * 256;
                 std::size_t got = 0;
-                rt(paris_hip_malloc_projection(ctx, static_cast<std::uint32_t>(h16_pitch / 4), n_col, &raw, &got), "half projection");
+                // the half copies of all slots, one under the other like d_all
+                rt(paris_hip_malloc_projection(ctx, static_cast<std::uint32_t>(h16_pitch / 4), n_col * static_cast<std::uint32_t>(slots), &raw, &got),
+                   "half projection");
                 d_half = reinterpret_cast<std::uint16_t*>(raw);
                 h16_pitch = got;
+                h16_stride = h16_pitch * n_col;
             }
 
             task t{};
@@ -240,9 +243,15 @@ namespace paris
                     if(filled == 0)
                         return;
                     const auto t1 = clock::now();
-                    rt(paris_hip_backproject_batch(ctx, d_buf[group * batch], d_pitch, d_stride, filled, n_row, n_col, d_v, t.subvol_geo.dim_x,
-                                                   t.subvol_geo.dim_y, dim_z, offset, &t.det_geo, &t.vol_geo, t.enable_roi, &t.roi, sines.data(),
-                                                   cosines.data(), delta_s, delta_t), "backproject()"); // :104
+                    if(po.f16)
+                        rt(paris_hip_backproject_batch_f16(ctx, reinterpret_cast<const std::uint16_t*>(reinterpret_cast<const char*>(d_half) + h16_stride * group * batch),
+                                                           h16_pitch, h16_stride, filled, n_row, n_col, d_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z,
+                                                           offset, &t.det_geo, &t.vol_geo, t.enable_roi, &t.roi, sines.data(), cosines.data(), delta_s,
+                                                           delta_t), "backproject()");
+                    else
+                        rt(paris_hip_backproject_batch(ctx, d_buf[group * batch], d_pitch, d_stride, filled, n_row, n_col, d_v, t.subvol_geo.dim_x,
+                                                       t.subvol_geo.dim_y, dim_z, offset, &t.det_geo, &t.vol_geo, t.enable_roi, &t.roi, sines.data(),
+                                                       cosines.data(), delta_s, delta_t), "backproject()"); // :104
                     rt(paris_hip_fence_record(ctx, fence[group]), "fence record"); // the group's slots are free once this has run
                     rep.enqueue_s += since(t1);
                     group = (group + 1u) % groups;
@@ -275,25 +284,14 @@ namespace paris
                         rt(paris_hip_stage_filter_rows(ctx, d_buf[slot], d_pitch, n_row, n_col, band_first, band_count, &t.det_geo), "filter()"); // :103
                     }
                     rt(paris_hip_stage_angle(&t.det_geo, p.idx, t.enable_angles, p.phi, &sines[filled], &cosines[filled]), "angle"); // src/backprojection.cpp:52-63
-                    if(po.f16)
-                    {
-                        if(band_count != 0)
-                            rt(paris_hip_convert_projection_f16(ctx, d_band, d_pitch,
-                                                                reinterpret_cast<std::uint16_t*>(reinterpret_cast<char*>(d_half) + static_cast<std::size_t>(band_first) * h16_pitch),
-                                                                h16_pitch, n_row, band_count), "to half");
-                        rt(paris_hip_backproject_f16(ctx, d_half, h16_pitch, n_row, n_col, d_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z,
-                                                     offset, &t.det_geo, &t.vol_geo, t.enable_roi, &t.roi, sines[0], cosines[0], delta_s, delta_t),
-                           "backproject()");
-                        rt(paris_hip_fence_record(ctx, fence[group]), "fence record");
-                        group = (group + 1u) % groups;
-                        rep.enqueue_s += since(t0);
-                    }
-                    else
-                    {
-                        rep.enqueue_s += since(t0);
-                        if(++filled == batch)
-                            flush();
-                    }
+                    if(po.f16 && band_count != 0) // BASELINE config 5: the filtered frame is rounded to IEEE half, its slot's band only
+                        rt(paris_hip_convert_projection_f16(ctx, d_band, d_pitch,
+                                                            reinterpret_cast<std::uint16_t*>(reinterpret_cast<char*>(d_half) + h16_stride * static_cast<std::size_t>(slot)
+                                                                                             + static_cast<std::size_t>(band_first) * h16_pitch),
+                                                            h16_pitch, n_row, band_count), "to half");
+                    rep.enqueue_s += since(t0);
+                    if(++filled == batch)
+                        flush();
                     ++rep.projections;
                 }
                 flush(); // the last, possibly partial group

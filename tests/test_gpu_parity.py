@@ -455,6 +455,37 @@ def test_backproject_f16_projections(be, oracle, kat_golden):
         assert_bit_equal(got, want)
 
 
+@pytest.mark.parametrize("dims,roi_x2", [((21, 42, 72), 82), ((21, 42, 71), 81)])
+def test_backproject_f16_batch_bit_exact(be, oracle, dims, roi_x2):
+    """paris_hip_backproject_batch_f16: the fused kernel on IEEE-half projections (one under the other in one buffer) equals
+    the oracle fed the half-rounded frames, in order, bit for bit; even and odd volume widths (lane widths 2 and 1)."""
+    g = (96, 80, 0.2, 0.25, -2.5, 1.25, 150, 250, 9.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(90, 50, 60, nat.l_vx_x * 1.1, nat.l_vx_x * 1.6, nat.l_vx_x * 1.4)
+    ovg = oracle.VolumeGeometry(90, 50, 60, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    roi, oroi = B.RegionOfInterest(10, roi_x2, 5, 47, 6, 51), oracle.RegionOfInterest(10, roi_x2, 5, 47, 6, 51)
+    n_proj, v_offset = 11, 12
+    frames = [(oracle.lcg_projection(96, 80, i) - np.float32(0.5)) * np.float32(2.5) for i in range(n_proj)]
+    want = np.zeros(dims, np.float32)
+    for i, p in enumerate(frames):
+        s, c, ds, dt = oracle.backproject_constants(odet, i)
+        oracle.backproject(want, p.astype(np.float16).astype(np.float32), v_offset, odet, ovg, s, c, ds, dt, oroi)
+    # the half frames, 80 rows each, in one pitched device buffer (the fp32 allocator with half the width)
+    stack = be.make_projection_device(48, 80 * n_proj)
+    halves = np.zeros((80 * n_proj, stack.pitch // 2), np.float16)
+    for i, p in enumerate(frames):
+        halves[80 * i:80 * (i + 1), :96] = p.astype(np.float16)
+    _lib.check(_lib.load().paris_hip_memcpy_volume_h2d(be._ctx, stack.ptr, halves.ctypes.data, stack.pitch // 4, 80 * n_proj, 1), "h2d")
+    sc = [B.stage_angle(det, i) for i in range(n_proj)]
+    d_v = be.make_volume_device(dims[2], dims[1], dims[0])
+    be.backproject_batch_f16(stack.ptr, stack.pitch, stack.pitch * 80, n_proj, 96, 80, d_v, v_offset, det, vg, True, roi,
+                             [s for s, _ in sc], [c for _, c in sc], det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
+    assert_bit_equal(volume_to_host(be, d_v), want)
+    be.free(d_v)
+    be.free(stack)
+
+
 def test_config5_grid_roi_slab_f16(be, oracle):
     """BASELINE config 5 in miniature on its real grid: 2048^2 detector, 4096^3 voxel grid (half the natural voxel
     size), ROI {1024..3072}^3, one 2048 x 2048 x 8 slab of the ROI (v_offset inside the ROI), fp16 projections.
