@@ -185,7 +185,15 @@ def main():
     info = sharding.make_subvolume_info(out_geo, world)  # one z-slab per rank
     z_first, z_count = sharding.slab_of_task(info, rank)
 
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    # One stream for everything in the step: torch's copies and fills and the library's kernels are ordered on it (a ctx with a
+    # private stream would run unordered beside torch's default-stream work). PARIS_BENCH_STREAM picks which stream, for A/B:
+    # "side" (default) = an explicit torch stream, "legacy" = the legacy default stream, "private" = the ctx's own stream (unordered
+    # with torch's work: timing only).
+    mode = os.environ.get("PARIS_BENCH_STREAM", "side")
+    if mode == "side":
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(side)
+    stream = None if mode == "private" else torch.cuda.current_stream(dev).cuda_stream
     be = B.Backend(dev_index, stream=stream, synchronous=False)
     be.set_backproject_tuning(args.vx, args.unroll, args.tz, args.lds_bytes)
 

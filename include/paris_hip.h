@@ -44,6 +44,7 @@ extern "C" {
 /* ctx flags */
 #define PARIS_HIP_CTX_DEFAULT 0u
 #define PARIS_HIP_CTX_SYNCHRONOUS 1u /* sync the stream before every call returns (reference behaviour) */
+#define PARIS_HIP_CTX_LEGACY_STREAM 2u /* with stream == NULL: enqueue on the legacy default stream instead of a private one */
 
 /* src/geometry.h:30-46, field for field */
 typedef struct paris_detector_geometry {
@@ -91,8 +92,9 @@ typedef struct paris_hip_ctx paris_hip_ctx;
 int paris_hip_device_count(int* count);
 
 /* Creates the per-device state. `stream` is a hipStream_t to enqueue on (e.g. the caller's torch stream),
- * or NULL to let the ctx create and own a non-blocking stream. Replaces set_device + all thread_local
- * statics. */
+ * or NULL to let the ctx create and own a non-blocking stream -- which is NOT ordered with work on the legacy
+ * default stream: a caller whose own work runs on the default stream (handle 0, e.g. PyTorch without an explicit
+ * stream) passes NULL together with PARIS_HIP_CTX_LEGACY_STREAM. Replaces set_device + all thread_local statics. */
 int paris_hip_ctx_create(int device, void* stream, unsigned flags, paris_hip_ctx** out);
 int paris_hip_ctx_destroy(paris_hip_ctx* ctx);
 /* synchronize_stream (src/cuda/stream.cpp) */

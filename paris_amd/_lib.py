@@ -14,6 +14,7 @@ ERROR_NO_DEVICE = 10002
 ERROR_UNSUPPORTED = 10003
 CTX_DEFAULT = 0
 CTX_SYNCHRONOUS = 1
+CTX_LEGACY_STREAM = 2
 
 
 class DetectorGeometry(C.Structure):

@@ -68,12 +68,17 @@ class FilterBuffer:
 
 class Backend:
     """One device + stream: the state the reference keeps in thread_local statics after set_device
-    (src/main.cpp:87). synchronous=True reproduces the reference's blocking calls."""
+    (src/main.cpp:87). synchronous=True reproduces the reference's blocking calls. stream: None = a private stream of
+    the ctx, a hipStream_t handle = that stream, 0 = the legacy default stream."""
 
     def __init__(self, device=0, stream=None, synchronous=True):
         self._L = _lib.load()
         ctx = C.c_void_p()
         flags = _lib.CTX_SYNCHRONOUS if synchronous else _lib.CTX_DEFAULT
+        if stream is not None and stream == 0:
+            # the caller's stream is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns unless a
+            # stream was set): enqueue there too, so that the caller's own work and these kernels stay ordered
+            flags |= _lib.CTX_LEGACY_STREAM
         check(self._L.paris_hip_ctx_create(device, C.c_void_p(stream) if stream else None, flags, C.byref(ctx)),
               "paris_hip_ctx_create")
         self._ctx = ctx
@@ -106,7 +111,8 @@ class Backend:
 
     @property
     def stream(self):
-        return self._L.paris_hip_ctx_stream(self._ctx)
+        """the hipStream_t handle the ctx enqueues on (0 = the legacy default stream)"""
+        return self._L.paris_hip_ctx_stream(self._ctx) or 0
 
     def free(self, obj):
         ptr = obj.ptr if hasattr(obj, "ptr") else obj

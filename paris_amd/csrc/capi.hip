@@ -70,9 +70,9 @@ extern "C" int paris_hip_ctx_create(int device, void* stream, unsigned flags, pa
         return static_cast<int>(hipErrorOutOfMemory);
     ctx->device = device;
     ctx->flags = flags;
-    if(stream != nullptr)
+    if(stream != nullptr || (flags & PARIS_HIP_CTX_LEGACY_STREAM))
     {
-        ctx->stream = static_cast<hipStream_t>(stream);
+        ctx->stream = static_cast<hipStream_t>(stream); // NULL = the legacy default stream
         ctx->owns_stream = false;
     }
     else
@@ -153,8 +153,7 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
     if(ctx == nullptr)
         return PARIS_HIP_SUCCESS;
     (void)hipSetDevice(ctx->device);
-    if(ctx->stream != nullptr)
-        (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream); // NULL: the legacy default stream
     if(ctx->upload_stream != nullptr)
         (void)hipStreamSynchronize(ctx->upload_stream);
     for(auto& kv : ctx->plans)

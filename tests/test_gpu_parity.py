@@ -840,6 +840,73 @@ def test_large_slab_properties(be, oracle):
     assert_bit_equal(run(2.0, z0, nz), full * np.float32(2.0))
 
 
+def test_full_size_2048_cube_properties(oracle):
+    """BASELINE config 3 at its full size -- the whole 2048^3 volume (32 GiB) from 2048^2 projections -- through
+    size-independent properties checked on the device (nothing this large goes through the oracle):
+    (a) z-slab identity: slab 5 of 8 computed on its own equals slices 1280..1535 of the full run, bit for bit;
+    (b) the fused kernel (three projections in one launch) equals the three single launches, bit for bit, everywhere;
+    (c) negation: adding p and then -p returns every voxel to exactly +0 (each product and sum is sign-symmetric);
+    (d) a 64 x 64 x 8 crop at the far corner equals the oracle's ROI run."""
+    import torch
+    n = 2048
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 80 * 2 ** 30:
+        pytest.skip("needs 80 GiB of free HBM")
+    g = (n, n, 0.2, 0.2, 0, 0, 500, 500, 0.25)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    l_vx = float(np.float32(nat.l_vx_x))
+    vg, ovg = B.VolumeGeometry(n, n, n, l_vx, l_vx, l_vx), oracle.VolumeGeometry(n, n, n, l_vx, l_vx, l_vx)
+    dev = torch.device("cuda", 0)
+    idxs = (3, 500, 1111)
+    frames = [oracle.lcg_projection(n, n, i) - np.float32(0.5) for i in idxs]
+    # stream 0 = the legacy default stream: torch's fills / comparisons and the library's kernels are ordered on it (a ctx
+    # with a private stream would race the 32 GiB torch.zeros below)
+    with B.Backend(0, stream=torch.cuda.current_stream(dev).cuda_stream, synchronous=False) as abe:
+        stack = torch.from_numpy(np.stack(frames)).to(dev)                       # (3, n, n), pitch n * 4
+        projs = [abe.wrap_projection(stack[j].data_ptr(), n * 4, n, n, idx=i, owner=stack) for j, i in enumerate(idxs)]
+        full = torch.zeros((n, n, n), device=dev)
+        d_full = abe.wrap_volume(full.data_ptr(), n, n, n, owner=full)
+        for p in projs:
+            B.backproject(abe, p, d_full, 0, det, vg, False, False, None)
+        # (a)
+        slab = torch.zeros((256, n, n), device=dev)
+        d_slab = abe.wrap_volume(slab.data_ptr(), n, n, 256, owner=slab)
+        for p in projs:
+            B.backproject(abe, p, d_slab, 1280, det, vg, False, False, None)
+        abe.synchronize()
+        assert torch.equal(slab.view(torch.int32), full[1280:1536].view(torch.int32))
+        del slab, d_slab
+        # (b)
+        fused = torch.zeros((n, n, n), device=dev)
+        d_fused = abe.wrap_volume(fused.data_ptr(), n, n, n, owner=fused)
+        sc = [B.stage_angle(det, i) for i in idxs]
+        abe.backproject_batch(stack.data_ptr(), n * 4, n * n * 4, 3, n, n, d_fused, 0, det, vg, False, None,
+                              [s for s, _ in sc], [c for _, c in sc], 0.0, 0.0)
+        abe.synchronize()
+        assert torch.equal(fused.view(torch.int32), full.view(torch.int32))
+        assert int(torch.count_nonzero(full)) > 0.5 * n ** 3
+        # (d)
+        crop = full[n - 8:, n - 64:, n - 64:].cpu().numpy()
+        roi = oracle.RegionOfInterest(n - 64, n, n - 64, n, n - 8, n)
+        want = np.zeros((8, 64, 64), np.float32)
+        for i, f in zip(idxs, frames):
+            s, c, ds, dt = oracle.backproject_constants(odet, i)
+            oracle.backproject(want, f, 0, odet, ovg, s, c, ds, dt, roi)
+        assert_bit_equal(crop, want)
+        # (c) on the fused copy: one projection and its negative
+        fused.zero_()
+        neg = (-stack[1:2]).contiguous()
+        p_neg = abe.wrap_projection(neg.data_ptr(), n * 4, n, n, idx=idxs[1], owner=neg)
+        B.backproject(abe, projs[1], d_fused, 0, det, vg, False, False, None)
+        abe.synchronize()
+        assert int(torch.count_nonzero(fused)) > 0.5 * n ** 3
+        B.backproject(abe, p_neg, d_fused, 0, det, vg, False, False, None)
+        abe.synchronize()
+        assert int(torch.count_nonzero(fused.view(torch.int32))) == 0            # every voxel is +0, not -0
+        del fused, full
+
+
 def test_config3_4_geometry_slab_crops(be, oracle):
     """BASELINE configs 3 / 4 geometry (2048^2 detector, 2048^3 grid): part of slab 7 of 8 (v_offset 1792, 24 slices =
     one and a half tiles deep) through the default kernel path (y-band tile order, 4-pixel staging, fast division),
@@ -1036,8 +1103,9 @@ def test_torch_memory_interop(be, oracle, kat_golden):
     det = B.DetectorGeometry(*KAT)
     vg = B.calculate_volume_geometry(det)
     dev = torch.device("cuda", 0)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = torch.cuda.current_stream(dev).cuda_stream   # 0 (the legacy default stream) unless the caller set one
     tb = B.Backend(0, stream=stream, synchronous=False)
+    assert tb.stream == stream                             # the ctx enqueues where torch does: both stay ordered
     vol = torch.zeros((61, 67, 67), dtype=torch.float32, device=dev)
     v = tb.wrap_volume(vol.data_ptr(), 67, 67, 61, owner=vol)
     for i in range(8):
@@ -1046,4 +1114,19 @@ def test_torch_memory_interop(be, oracle, kat_golden):
         B.backproject(tb, p, v, 0, det, vg, False, False, None)
     torch.cuda.synchronize()
     assert_bit_equal(vol.cpu().numpy(), kat_golden["volume"])
+    tb.close()
+    # the same on an explicit torch stream: tensor fills, copies and the kernels are ordered on it without any host sync
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        tb = B.Backend(0, stream=side.cuda_stream, synchronous=False)
+        assert tb.stream == side.cuda_stream != 0
+        big = torch.full((61, 67, 67), 7.0, dtype=torch.float32, device=dev)
+        big.zero_()                                       # still running when the first kernel is enqueued
+        v = tb.wrap_volume(big.data_ptr(), 67, 67, 61, owner=big)
+        frames = torch.from_numpy(kat_golden["filtered"]).pin_memory().to(dev, non_blocking=True)
+        for i in range(8):
+            p = tb.wrap_projection(frames[i].data_ptr(), 64 * 4, 64, 48, idx=i, owner=frames)
+            B.backproject(tb, p, v, 0, det, vg, False, False, None)
+        out = big.cpu()
+    assert_bit_equal(out.numpy(), kat_golden["volume"])
     tb.close()

@@ -22,6 +22,7 @@ nat = B.calculate_volume_geometry(det)
 l_vx = float(np.float32(nat.l_vx_x))
 vg = B.VolumeGeometry(n, n, n, l_vx, l_vx, l_vx)
 dev = torch.device("cuda", 0)
+torch.cuda.set_stream(torch.cuda.Stream(device=dev))  # torch's copies and the library's kernels on one explicit stream
 be = B.Backend(0, stream=torch.cuda.current_stream(dev).cuda_stream, synchronous=False)
 raw = torch.rand((8, n, n), device=dev)
 work = torch.empty_like(raw)
