@@ -4,6 +4,7 @@
 // vectoriser turns its fp32 multiplies and adds into v_pk_mul_f32 / v_pk_add_f32, which on gfx950 issue at half the
 // rate of the plain instructions (tools/pkbench.hip) and need v_mov packing on top: -fno-slp-vectorize (Makefile) is
 // worth +12 % here, while the memory-bound tile kernel in backproject.hip is indifferent to it.
+#define PARIS_BP_SINGLE_INSTRUCTION_FLOOR 1
 #include "bp_device.h"
 
 namespace

@@ -11,6 +11,13 @@
 #include <cstring>
 #include <type_traits>
 
+// 1: the fast path takes floor(v) with v_cvt_flr_i32_f32 and the row weight with v_fract_f32 (one instruction less per
+// voxel-update; both exhaustively equal to the floorf forms, tools/flr_probe.hip). Worth +1 % in the ALU-bound fused kernel,
+// which sets it; the memory-bound tile kernel measured 0.3 % slower with the inline asm in its loop and keeps the plain form.
+#ifndef PARIS_BP_SINGLE_INSTRUCTION_FLOOR
+#define PARIS_BP_SINGLE_INSTRUCTION_FLOOR 0
+#endif
+
 namespace
 {
     struct BpParams
@@ -393,9 +400,20 @@ namespace
                                                         const Column& col)
     {
         const float v = v_coordinate<FD>(g, z_m, col.factor);
-        const float y1 = floorf(v);
-        const float y2 = y1 + 1.f;
-        const int y1i = static_cast<int>(y1);
+        float y1 = 0.f, y2 = 0.f;
+        int y1i;
+        if(FAST && PARIS_BP_SINGLE_INSTRUCTION_FLOOR)
+        {
+            // floor(v) as an integer in one instruction; its float form is not needed on this path (the row weights come from
+            // v_fract below). tools/flr_probe.hip checks both single-instruction forms against floorf for every fp32 value.
+            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(y1i) : "v"(v));
+        }
+        else
+        {
+            y1 = floorf(v);
+            y2 = y1 + 1.f;
+            y1i = static_cast<int>(y1);
+        }
         const int rrel = y1i - b.by0;
         const int bhs_m2 = b.bhs - 2;
         bool valid;
@@ -449,7 +467,8 @@ namespace
         // For a valid tap (v >= 0) both v - y1 and y2 - v are exact: below 1 they are v and RN(1 - v), from 1 up multiples
         // of ulp(v) >= 2^-23 inside [0, 1]. So y2 - v == 1 - (v - y1) bit for bit, and the fast path (which does not need y2
         // for its validity test) saves the addition; for an invalid tap the value is discarded below.
-        const float wy1 = v - y1;
+        // v_fract_f32(v) == v - floor(v) bit for bit for 0 <= v < 2^24, i.e. for every valid tap (exhaustive: tools/flr_probe.hip)
+        const float wy1 = (FAST && PARIS_BP_SINGLE_INSTRUCTION_FLOOR) ? __builtin_amdgcn_fractf(v) : v - y1;
         const float wy2 = FAST ? 1.f - wy1 : y2 - v;
         float det = wy2 * interp_y1 + wy1 * interp_y2;
         det = valid ? det : 0.f;         // :71
