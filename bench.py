@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--lds-bytes", type=int, default=0)
     ap.add_argument("--fused-steps", type=int, default=4, help="extra steps with the fused multi-projection kernel, "
                     "reported as fused_extension next to the headline (0 disables)")
+    ap.add_argument("--fused-batch", type=int, default=16, help="projections per fused launch in fused_extension and "
+                    "deferred_boundary (2..32; the headline step keeps --batch single-projection launches)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of the N > 1 path "
                     "with several ranks sharing one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default: LOCAL_RANK)")
@@ -200,14 +202,16 @@ def main():
     n_row, n_col = w["n_row"], w["n_col"]
     gen = torch.Generator(device=dev)
     gen.manual_seed(12345 + rank)
-    raw = torch.rand((args.batch, n_col, n_row), generator=gen, device=dev, dtype=torch.float32)
+    fb = max(2, min(32, args.fused_batch))
+    nb = max(args.batch, fb)
+    raw = torch.rand((nb, n_col, n_row), generator=gen, device=dev, dtype=torch.float32)
     work = torch.empty_like(raw)
     vol = torch.zeros((z_count, out_geo.dim_y, out_geo.dim_x), device=dev, dtype=torch.float32)
     d_vol = be.wrap_volume(vol.data_ptr(), out_geo.dim_x, out_geo.dim_y, z_count, owner=vol)
     f16 = bool(w.get("f16"))
     half = torch.empty((n_col, n_row), device=dev, dtype=torch.float16) if f16 else None
     pitch = work.stride(1) * 4
-    projs = [be.wrap_projection(work[b].data_ptr(), pitch, n_row, n_col, owner=work) for b in range(args.batch)]
+    projs = [be.wrap_projection(work[b].data_ptr(), pitch, n_row, n_col, owner=work) for b in range(nb)]
 
     # f4: the detector rows this rank's slab can read for any angle; rows outside never reach its voxels
     band_first, band_count = 0, n_col
@@ -263,11 +267,11 @@ def main():
     if args.fused_steps > 0:
         sc = [B.stage_angle(det, b) for b in range(w["n_proj"])]
         stride = work.stride(0) * 4
-        halves = torch.empty((args.batch, n_col, n_row), device=dev, dtype=torch.float16) if f16 else None
+        halves = torch.empty((fb, n_col, n_row), device=dev, dtype=torch.float16) if f16 else None
 
         def fused_step(s):
-            idx = [(s * args.batch + b) % w["n_proj"] for b in range(args.batch)]
-            for b in range(args.batch):
+            idx = [(s * fb + b) % w["n_proj"] for b in range(fb)]
+            for b in range(fb):
                 work[b, band].copy_(raw[b, band], non_blocking=True)
                 B.weight_rows(be, projs[b], det, band_first, band_count)
                 B.filter_rows(be, projs[b], det, band_first, band_count)
@@ -275,10 +279,10 @@ def main():
                     B._lib.check(be._L.paris_hip_convert_projection_f16(be._ctx, projs[b].ptr, pitch, halves[b].data_ptr(), n_row * 2,
                                                                        n_row, n_col), "paris_hip_convert_projection_f16")
             if f16:
-                be.backproject_batch_f16(halves.data_ptr(), n_row * 2, n_row * n_col * 2, args.batch, n_row, n_col, d_vol, z_first, det,
+                be.backproject_batch_f16(halves.data_ptr(), n_row * 2, n_row * n_col * 2, fb, n_row, n_col, d_vol, z_first, det,
                                          vol_geo, roi is not None, roi, [sc[i][0] for i in idx], [sc[i][1] for i in idx], 0.0, 0.0)
             else:
-                be.backproject_batch(work.data_ptr(), pitch, stride, args.batch, n_row, n_col, d_vol, z_first, det, vol_geo,
+                be.backproject_batch(work.data_ptr(), pitch, stride, fb, n_row, n_col, d_vol, z_first, det, vol_geo,
                                      roi is not None, roi, [sc[i][0] for i in idx], [sc[i][1] for i in idx], 0.0, 0.0)
 
         fused_step(0)
@@ -302,14 +306,15 @@ def main():
         # ---- the same per-projection calls as the headline, with the library's deferral switched on: every
         # paris_hip_backproject call snapshots its projection, `batch` of them are added by one fused launch
         # (fp32 calls only; the half-precision entry point is not deferred)
-        be.set_backproject_deferral(1 if f16 else args.batch)
+        be.set_backproject_deferral(1 if f16 else fb)
+        d_steps = args.fused_steps * max(1, -(-fb // args.batch))  # whole groups of fb projections
         step(0)
         be.flush()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         td0 = time.perf_counter()
-        for s in range(args.fused_steps):
+        for s in range(d_steps):
             step(1 + s)
         be.flush()
         torch.cuda.synchronize()
@@ -321,6 +326,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             td = float(t.item())
         fused["deferred_seconds"] = td
+        fused["deferred_projections"] = d_steps * args.batch
     voxels_rank = float(z_count) * out_geo.dim_x * out_geo.dim_y
     voxels_all = float(out_geo.dim_z) * out_geo.dim_x * out_geo.dim_y
     updates_all = voxels_all * args.batch * args.steps
@@ -362,17 +368,18 @@ def main():
             },
         }
         if fused is not None:
-            per_launch = voxels_rank * args.batch
+            per_launch = voxels_rank * fb
             out["fused_extension"] = {
-                "what": "same step, but one fused launch adds all %d projections of the batch (paris_hip_backproject_batch; "
-                        "bit-identical volume); not the headline because the plugin boundary is one projection per call"
-                        % args.batch,
-                "value": voxels_all * args.batch * fused["steps"] / fused["seconds"] / 1e9,
+                "what": "the same per-projection copy + weight + filter, but one fused launch adds %d projections "
+                        "(paris_hip_backproject_batch; bit-identical volume); not the headline because the plugin boundary is one "
+                        "projection per call" % fb,
+                "value": voxels_all * fb * fused["steps"] / fused["seconds"] / 1e9,
                 "unit": "GVoxel-updates/s",
                 "kernel_ms_per_launch": fused["kernel_ms"],
                 "kernel_GVox_per_s_per_gpu": per_launch / (fused["kernel_ms"] * 1e-3) / 1e9 if fused["kernel_ms"] > 0 else 0.0,
-                "algorithmic_bytes_per_update": 8.0 / args.batch,
-                "hbm_GBps": (8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col * args.batch) / (fused["kernel_ms"] * 1e-3) / 1e9
+                "algorithmic_bytes_per_update": 8.0 / fb,
+                "projections_per_launch": fb,
+                "hbm_GBps": (8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col * fb) / (fused["kernel_ms"] * 1e-3) / 1e9
                             if fused["kernel_ms"] > 0 else 0.0,
                 "bound": "vector ALU issue (HBM term divided by the batch size)",
             }
@@ -381,8 +388,8 @@ def main():
                     "what": "the headline's step unchanged -- one paris_hip_backproject call per projection -- with "
                             "paris_hip_set_backproject_deferral(%d): the library snapshots each call's projection and adds %d of "
                             "them per fused launch (bit-identical volume); what PARIS's per-projection loop gets through paris::hip"
-                            % (args.batch, args.batch),
-                    "value": voxels_all * args.batch * fused["steps"] / fused["deferred_seconds"] / 1e9,
+                            % (fb, fb),
+                    "value": voxels_all * fused["deferred_projections"] / fused["deferred_seconds"] / 1e9,
                     "unit": "GVoxel-updates/s",
                 }
         if world == 1 and args.cpu_budget > 0:
