@@ -73,6 +73,16 @@ int main(int argc, char** argv)
                     throw paris::stage_construction_error{"missing value for " + k};
                 return argv[++a];
             };
+            if(k == "--help" || k == "-h")
+            {
+                std::printf("paris.hip --geometry geo.ini --input <dir of .his files> --output <dir> [--name vol] [--angles file] [--quality q]\n"
+                            "          [--roi --roi-x1 a --roi-x2 b --roi-y1 c --roi-y2 d --roi-z1 e --roi-z2 f]\n"
+                            "          [--slabs n] [--devices n] [--f16] [--window ramp|shepp-logan] [--batch n] [--no-row-band]\n"
+                            "          [--drain-chunk-kib n]\n"
+                            "geo.ini: key=value lines for n_row n_col l_px_row l_px_col delta_s delta_t d_so d_od delta_phi\n"
+                            "Reconstructs the HIS projections of <dir> (sorted by path) into <output>/<name>.ddbvf on all MI355X of the node.\n");
+                return 0;
+            }
             if(k == "--geometry") geometry = val();
             else if(k == "--input") po.input_path = val();
             else if(k == "--output") po.output_path = val();
