@@ -170,6 +170,46 @@ def test_apply_filter(be, oracle, n_row, n_col, variant):
     be.free(k)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PARIS_FILTER_FUZZ_SEEDS", "10"))))
+def test_weight_and_filter_random_sizes(be, oracle, seed):
+    """Seeded random detector sizes (odd and even row counts, widths on both sides of the power-of-two boundaries where the
+    filter switches kernels and lengths), pixel pitches and offsets: weighting bit-exact, filter within FFT rounding of the
+    oracle and of a float64 FFT, through the stage wrappers and through a row band of the same frame."""
+    rng = np.random.default_rng(4000 + seed)
+    n_row = int(rng.choice([rng.integers(3, 64), rng.integers(64, 513), rng.integers(500, 1030), rng.integers(1020, 2060),
+                            rng.integers(2040, 4100), 512, 513, 1024, 1025, 2048]))
+    n_col = int(rng.integers(1, 70))
+    g = (n_row, n_col, float(rng.choice([0.1, 0.2, 0.127, 0.4])), float(rng.choice([0.1, 0.2, 0.25])), float(rng.uniform(-5, 5)),
+         float(rng.uniform(-5, 5)), float(rng.uniform(50, 600)), float(rng.uniform(50, 600)), 1.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    p = (oracle.lcg_projection(n_row, n_col, seed) - np.float32(0.4)) * np.float32(rng.uniform(0.5, 200))
+    d_p = to_device(be, p)
+    B.weight(be, d_p, det)
+    want_w = oracle.weight(p.copy(), odet)
+    got_w = to_host(be, d_p)
+    assert np.array_equal(got_w.view(np.uint32), want_w.view(np.uint32))
+    B.filter(be, d_p, det)
+    got = to_host(be, d_p)
+    fs = oracle.filter_size(n_row)
+    want = oracle.apply_filter(want_w.copy(), oracle.make_filter(fs, det.l_px_row), fs)
+    scale = max(np.abs(want).max(), 1e-30)
+    assert np.max(np.abs(got - want)) <= FILTER_TOL * scale
+    kk = det.l_px_row * np.abs(np.fft.rfft(oracle.make_filter_real(fs, det.l_px_row).astype(np.float64)))
+    exact = np.fft.irfft(np.fft.rfft(want_w.astype(np.float64), fs, axis=1) * kk[None, :], fs, axis=1)[:, :n_row]
+    assert np.max(np.abs(got - exact)) <= FILTER_TOL * scale
+    be.free(d_p)
+    # the same rows through the band entry points (whole filter row pairs): bit-identical to the full call
+    first = 2 * int(rng.integers(0, max(1, n_col // 2)))
+    count = min(n_col - first, 2 * int(rng.integers(1, 8)))
+    d_q = to_device(be, p)
+    B.weight_rows(be, d_q, det, first, count)
+    B.filter_rows(be, d_q, det, first, count)
+    band = to_host(be, d_q)
+    be.free(d_q)
+    assert np.array_equal(band[first:first + count].view(np.uint32), got[first:first + count].view(np.uint32))
+    assert np.array_equal(band[:first], p[:first]) and np.array_equal(band[first + count:], p[first + count:])
+
+
 def test_filter_wrapper_and_golden(be, oracle, kat_golden):
     det = B.DetectorGeometry(*KAT)
     for i in (0, 7):
