@@ -198,3 +198,26 @@ def test_frame_stream_equals_the_queueing_source(io, tmp_path, number_type, imag
     rc = io.paris_io_stream_scan(str(d).encode(), 0, None, 1, w + 1, h, 0, h, 0, C.byref(n), idx, phi, data.ctypes.data_as(_fp),
                                  C.byref(skipped))
     assert rc == 3
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_his_reader_random_files(io, tmp_path, seed):
+    """Seeded random HIS files: every number type, rectangle origins other than (1, 1), image headers of any size,
+    1..5 frames of random size. The C++ reader == the Python restatement of src/his.cpp:105-198, value for value."""
+    rng = np.random.default_rng(900 + seed)
+    number_type = int(rng.choice([2, 4, 32, 64, 128]))
+    w, h, n = int(rng.integers(1, 70)), int(rng.integers(1, 50)), int(rng.integers(1, 6))
+    ulx, uly = int(rng.integers(0, 2000)), int(rng.integers(0, 2000))
+    img_hdr = int(rng.choice([0, 1, 32, 100, 513]))
+    if number_type in (64, 128):
+        frames = (rng.standard_normal((n, h, w)) * 1000).astype(np.float64 if number_type == 64 else np.float32)
+    else:
+        hi = {2: 256, 4: 65536, 32: 2 ** 32}[number_type]
+        frames = rng.integers(0, hi, size=(n, h, w), dtype=np.uint64)
+    p = tmp_path / "f.his"
+    p.write_bytes(F.his_file_bytes(frames, number_type, img_hdr, ulx=ulx, uly=uly))
+    got, want = his_load(io, p), F.his_read(p)
+    assert len(got) == len(want) == n
+    for a, b in zip(got, want):
+        assert a.shape == b.shape == (h, w)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
