@@ -15,6 +15,7 @@ from paris_amd import backend as B  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--slices", type=int, default=2048)
 ap.add_argument("--rounds", type=int, default=4)
+ap.add_argument("--z-first", type=int, default=-1, help="first slice of the slab (default: centred)")
 ap.add_argument("--configs", default="8:16:2:2:1", help="order:tz:unroll:nt:vec4[:vx[:lds_bytes]][,...]")
 args = ap.parse_args()
 n = 2048
@@ -24,7 +25,7 @@ vg = B.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
 be = B.Backend(0, synchronous=False)
 d_p = B.load(be, B.Projection(np.random.default_rng(1).random((n, n), dtype=np.float32), n, n))
 d_v = be.make_volume_device(n, n, args.slices)
-z_first = (n - args.slices) // 2
+z_first = args.z_first if args.z_first >= 0 else (n - args.slices) // 2
 cfgs = [tuple(int(x) for x in c.split(":")) for c in args.configs.split(",")]
 ms = {c: [] for c in cfgs}
 angles = (0, 45, 100, 200, 300)
