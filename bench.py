@@ -4,9 +4,11 @@
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Metric (BASELINE.json): GVoxel-updates/s = voxels x projections / seconds / 1e9, whole job over all N GPUs.
-A step is one pass of the hot path over one batch of `--batch` synthetic projections: for each projection a
-device copy of the raw frame into the work buffer (stands in for the upload), paris::weight, paris::filter,
-paris::backproject into the rank's z-slab. Inputs are resident in HBM before the timed region starts.
+A step is one pass of the hot path over one batch of synthetic projections: for each projection a device copy of
+the raw frame into the work buffer (stands in for the upload), paris::weight, paris::filter, paris::backproject
+into the rank's z-slab. Inputs are resident in HBM before the timed region starts. The batch defaults to
+ceil(n_proj / steps): the K timed steps are the WHOLE job of the workload (all 1440 projections of config 3, the full
+circle), projection index = position in the job; `--batch B` restores a fixed batch (a partial arc, flagged in config).
 
 Workloads (BASELINE.json configs; geometry per SURVEY.md 8d: l_px 0.2 mm, d_so = d_od = 500 mm, no offsets):
   c3 (default)  2048^3 volume, 1440 projections @ 2048x2048 fp32. N = 1: the whole volume on one GPU (config 3,
@@ -127,28 +129,99 @@ def cpu_baseline(w, budget_s):
     }
 
 
+VALU_PEAK_LANE_INSTR = 58.12e12  # plain fp32 v_mul_f32 lane-instructions/s on this chip (tools/pkbench.hip, profiles/r01_pkbench.txt)
+
+
+def fused_sq_profile():
+    """VALU instructions per voxel-update of the fused kernel from the newest committed SQ counter profile
+    (rocprofv3 --pmc SQ_INSTS_VALU ...: counters cannot be read from inside this process)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sq_counters*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for name, k in d.get("kernels", {}).items():
+            if name.startswith("bp_fused_kernel"):
+                return k["derived"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def fused_report(fused, fb, f16, voxels_rank, voxels_all, n_row, n_col, per_launch):
+    rate = per_launch / (fused["kernel_ms"] * 1e-3) if fused["kernel_ms"] > 0 else 0.0  # voxel-updates/s of the kernel
+    hbm_gbps = ((8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col * fb) / (fused["kernel_ms"] * 1e-3) / 1e9
+                if fused["kernel_ms"] > 0 else 0.0)
+    rep = {
+        "what": "the same per-projection copy + weight + filter, but one fused launch adds %d projections "
+                "(paris_hip_backproject_batch; bit-identical volume); not the headline because the plugin boundary is one "
+                "projection per call" % fb,
+        "value": voxels_all * fb * fused["steps"] / fused["seconds"] / 1e9,
+        "unit": "GVoxel-updates/s",
+        "kernel_ms_per_launch": fused["kernel_ms"],
+        "kernel_ms_min_max": [fused["kernel_ms_min"], fused["kernel_ms_max"]],
+        "kernel_GVox_per_s_per_gpu": rate / 1e9,
+        "algorithmic_bytes_per_update": 8.0 / fb,
+        "projections_per_launch": fb,
+        "hbm_GBps": hbm_gbps,
+        "hbm_frac": hbm_gbps / HBM_PEAK_GBS,
+    }
+    derived, src = fused_sq_profile()
+    if derived is not None:
+        ipu = derived["valu_instructions_per_voxel_update"]
+        achieved = rate * ipu  # lane-instructions/s: one lane executes `ipu` vector instructions per voxel-update
+        rep["roofline"] = {
+            "bound": "valu_issue", "achieved": achieved / 1e12, "peak": VALU_PEAK_LANE_INSTR / 1e12,
+            "unit": "T lane-instr/s", "frac": achieved / VALU_PEAK_LANE_INSTR,
+            "valu_instructions_per_voxel_update": ipu,
+            "lds_bank_conflict_share_of_lds_cycles": derived.get("lds_bank_conflict_share_of_lds_cycles"),
+            "source": "%s (SQ_INSTS_VALU per voxel-update) x this run's kernel rate; peak = plain v_mul_f32 issue rate, "
+                      "profiles/r01_pkbench.txt" % src,
+        }
+    else:
+        rep["roofline"] = None
+    return rep
+
+
+def octant_stats(kernel_ms, idx_of_launch, n_proj):
+    """min / mean / max kernel time per 45-degree octant of the projection angle (phi = idx * 360 / n_proj)"""
+    bins = [[] for _ in range(8)]
+    for ms, idx in zip(kernel_ms, idx_of_launch):
+        bins[min(7, int(8.0 * (idx % n_proj) / n_proj))].append(ms)
+    out = []
+    for o, b in enumerate(bins):
+        if b:
+            out.append({"deg": [45 * o, 45 * (o + 1)], "launches": len(b), "min_ms": min(b), "mean_ms": sum(b) / len(b),
+                        "max_ms": max(b)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
-    ap.add_argument("--batch", type=int, default=8, help="projections per step")
+    ap.add_argument("--batch", type=int, default=0, help="projections per step; 0 (default) = ceil(n_proj / steps), i.e. the "
+                    "timed steps are the whole job")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline (0 disables)")
     ap.add_argument("--vx", type=int, default=0)
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--tz", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
-    ap.add_argument("--fused-steps", type=int, default=4, help="extra steps with the fused multi-projection kernel, "
-                    "reported as fused_extension next to the headline (0 disables)")
+    ap.add_argument("--fused-steps", type=int, default=8, help="extra steps with the fused multi-projection kernel, "
+                    "reported as fused_extension next to the headline (0 disables); the steps are spread over the circle")
     ap.add_argument("--fused-batch", type=int, default=16, help="projections per fused launch in fused_extension and "
-                    "deferred_boundary (2..32; the headline step keeps --batch single-projection launches)")
+                    "deferred_boundary (2..32; the headline step keeps single-projection launches)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of the N > 1 path "
                     "with several ranks sharing one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default: LOCAL_RANK)")
     ap.add_argument("--row-band", type=int, default=1, help="1 (default): each rank uploads, weights and filters only the "
                     "detector rows its z-slab can read (paris_hip_slab_row_band; the whole detector at N = 1); 0: all rows")
     ap.add_argument("--slices", type=int, default=0, help="rehearsal only: cap the volume depth (0 = the workload's)")
+    ap.add_argument("--final-gather", choices=["checksums", "slabs", "off"], default="checksums",
+                    help="N > 1, after the timed region and timed separately: the job's one collective. checksums (default): "
+                    "all-gather of per-slab checksums; slabs: the slabs themselves gathered on rank 0 (4 GiB each at N = 8)")
     args = ap.parse_args()
 
     import torch
@@ -161,9 +234,10 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible -- the hot path has no CPU fallback")
+    from paris_amd import sharding
+
     n_visible = torch.cuda.device_count()
-    # a launcher may give every rank its own single visible device (ROCR/HIP_VISIBLE_DEVICES): then LOCAL_RANK wraps
-    dev_index = args.device if args.device >= 0 else (local_rank if local_rank < n_visible else local_rank % n_visible)
+    dev_index = sharding.device_of_rank(local_rank, n_visible, args.device)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -173,9 +247,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
         else:
             dist.init_process_group(backend=args.dist_backend)
+        # every rank must sit on a GPU of its own (RCCL needs it; a wrapped LOCAL_RANK would silently halve the job's HBM)
+        placement = sharding.gather_placement(dist, dev_index, torch.cuda.get_device_properties(dev_index))
+        sharding.check_placement(placement, exclusive=(args.dist_backend == "nccl"))
 
     from paris_amd import backend as B
-    from paris_amd import sharding
 
     w = dict(WORKLOADS[args.workload])
     if args.slices > 0:
@@ -199,11 +275,12 @@ def main():
     be = B.Backend(dev_index, stream=stream, synchronous=False)
     be.set_backproject_tuning(args.vx, args.unroll, args.tz, args.lds_bytes)
 
-    n_row, n_col = w["n_row"], w["n_col"]
+    n_row, n_col, n_proj = w["n_row"], w["n_col"], w["n_proj"]
+    batch = args.batch if args.batch > 0 else -(-n_proj // max(1, args.steps))
     gen = torch.Generator(device=dev)
     gen.manual_seed(12345 + rank)
     fb = max(2, min(32, args.fused_batch))
-    nb = max(args.batch, fb)
+    nb = max(16, fb)  # work slots and distinct raw frames; a step cycles through them (stream order makes the reuse safe)
     raw = torch.rand((nb, n_col, n_row), generator=gen, device=dev, dtype=torch.float32)
     work = torch.empty_like(raw)
     vol = torch.zeros((z_count, out_geo.dim_y, out_geo.dim_x), device=dev, dtype=torch.float32)
@@ -219,10 +296,13 @@ def main():
         band_first, band_count = B.slab_row_band(det, vol_geo, out_geo.dim_x, out_geo.dim_y, z_count, z_first, roi)
     band = slice(band_first, band_first + band_count)
 
-    def step(s):
-        for b in range(args.batch):
+    launched = []  # projection index of every single-projection backprojection call, in call order
+
+    def step(first_idx, count=None):
+        for j in range(batch if count is None else count):
+            b = j % nb
             p = projs[b]
-            p.idx = (s * args.batch + b) % w["n_proj"]
+            p.idx = (first_idx + j) % n_proj
             work[b, band].copy_(raw[b, band], non_blocking=True)              # stands in for the upload
             B.weight_rows(be, p, det, band_first, band_count)                 # src/main.cpp:102
             B.filter_rows(be, p, det, band_first, band_count)                 # :103
@@ -233,6 +313,7 @@ def main():
                 be.backproject_f16(half.data_ptr(), n_row * 2, n_row, n_col, d_vol, z_first, det, vol_geo, True, roi, sn, cs, 0.0, 0.0)
             else:
                 B.backproject(be, p, d_vol, z_first, det, vol_geo, False, roi is not None, roi)  # :104
+            launched.append(p.idx)
 
     def barrier():
         if dist is not None:
@@ -241,36 +322,44 @@ def main():
             else:
                 dist.barrier()
 
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # warmup steps run the projections just before index 0 (the end of the circle), the timed steps the job from index 0
     for s in range(args.warmup):
-        step(s)
+        step((s - args.warmup) * batch)
     torch.cuda.synchronize()
-    be.backproject_timing_arm(min(65536, max(1, args.steps * args.batch)))
+    timed_launches = args.steps * batch
+    be.backproject_timing_arm(min(65536, max(1, timed_launches)))
+    del launched[:]
 
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        step(args.warmup + s)
+        step(s * batch)
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     kernel_ms = be.backproject_timing_collect()
+    kernel_idx = launched[-len(kernel_ms):] if kernel_ms else []
 
     # ---- extension, outside the headline: the same step with ONE fused launch per batch (paris_hip_backproject_batch)
     fused = None
     if args.fused_steps > 0:
-        sc = [B.stage_angle(det, b) for b in range(w["n_proj"])]
+        sc = [B.stage_angle(det, b) for b in range(n_proj)]
         stride = work.stride(0) * 4
         halves = torch.empty((fb, n_col, n_row), device=dev, dtype=torch.float16) if f16 else None
+        # the fused steps start at evenly spaced angles of the circle (consecutive projections inside a launch)
+        starts = [(s * n_proj) // args.fused_steps for s in range(args.fused_steps)]
 
-        def fused_step(s):
-            idx = [(s * fb + b) % w["n_proj"] for b in range(fb)]
+        def fused_step(first_idx):
+            idx = [(first_idx + b) % n_proj for b in range(fb)]
             for b in range(fb):
                 work[b, band].copy_(raw[b, band], non_blocking=True)
                 B.weight_rows(be, projs[b], det, band_first, band_count)
@@ -285,57 +374,71 @@ def main():
                 be.backproject_batch(work.data_ptr(), pitch, stride, fb, n_row, n_col, d_vol, z_first, det, vol_geo,
                                      roi is not None, roi, [sc[i][0] for i in idx], [sc[i][1] for i in idx], 0.0, 0.0)
 
-        fused_step(0)
+        fused_step(n_proj - fb)
         torch.cuda.synchronize()
         be.backproject_timing_arm(args.fused_steps)
         barrier()
         torch.cuda.synchronize()
         tf0 = time.perf_counter()
-        for s in range(args.fused_steps):
-            fused_step(1 + s)
+        for first in starts:
+            fused_step(first)
         torch.cuda.synchronize()
         barrier()
-        tf = time.perf_counter() - tf0
-        if dist is not None:
-            t = torch.tensor([tf], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tf = float(t.item())
+        tf = max_over_ranks(time.perf_counter() - tf0)
         fms = be.backproject_timing_collect()
-        fused = {"steps": args.fused_steps, "seconds": tf, "kernel_ms": sum(fms) / max(1, len(fms))}
+        fused = {"steps": args.fused_steps, "seconds": tf, "kernel_ms": sum(fms) / max(1, len(fms)),
+                 "kernel_ms_min": min(fms) if fms else 0.0, "kernel_ms_max": max(fms) if fms else 0.0}
 
         # ---- the same per-projection calls as the headline, with the library's deferral switched on: every
         # paris_hip_backproject call snapshots its projection, `batch` of them are added by one fused launch
         # (fp32 calls only; the half-precision entry point is not deferred)
         be.set_backproject_deferral(1 if f16 else fb)
-        d_steps = args.fused_steps * max(1, -(-fb // args.batch))  # whole groups of fb projections
-        step(0)
+        step(n_proj - fb, fb)
         be.flush()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         td0 = time.perf_counter()
-        for s in range(d_steps):
-            step(1 + s)
+        for first in starts:
+            step(first, fb)
         be.flush()
         torch.cuda.synchronize()
         barrier()
-        td = time.perf_counter() - td0
+        td = max_over_ranks(time.perf_counter() - td0)
         be.set_backproject_deferral(1)
-        if dist is not None:
-            t = torch.tensor([td], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            td = float(t.item())
         fused["deferred_seconds"] = td
-        fused["deferred_projections"] = d_steps * args.batch
+        fused["deferred_projections"] = len(starts) * fb
+
+    # ---- the job's one collective (north star: "no RCCL collective needed beyond a final gather"), timed on its own
+    gather = None
+    if dist is not None and world > 1 and args.final_gather != "off":
+        on_device = args.dist_backend == "nccl"
+        barrier()
+        torch.cuda.synchronize()
+        tg0 = time.perf_counter()
+        res = sharding.final_gather(dist, vol, info, rank, world, full=(args.final_gather == "slabs"), on_device=on_device)
+        torch.cuda.synchronize()
+        barrier()
+        tg = max_over_ranks(time.perf_counter() - tg0)
+        gather = {"mode": args.final_gather, "seconds": tg, "backend": "rccl" if on_device else args.dist_backend,
+                  "rccl_ranks_seen": dist.get_world_size(), "slab_checksums": res["checksums"],
+                  "checksum_of_checksums": res["checksum_of_checksums"]}
+        if res.get("gathered_bytes"):
+            gather["gathered_bytes"] = res["gathered_bytes"]
+            gather["GBps_into_rank0"] = res["gathered_bytes"] / tg / 1e9
+            gather["gathered_matches_checksums"] = res.get("gathered_matches_checksums")
+
     voxels_rank = float(z_count) * out_geo.dim_x * out_geo.dim_y
     voxels_all = float(out_geo.dim_z) * out_geo.dim_x * out_geo.dim_y
-    updates_all = voxels_all * args.batch * args.steps
+    updates_all = voxels_all * batch * args.steps
 
     if rank == 0:
         traffic, traffic_src = measured_traffic(w, world)
         avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         algo_bytes = 8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col  # per launch: RMW of the slab + one projection pass
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        distinct = len(set(kernel_idx))
+        octants = octant_stats(kernel_ms, kernel_idx, n_proj)
         out = {
             "metric": "GVoxel-updates/s (voxels x projections / s), FDK hot path weight+filter+backproject",
             "value": updates_all / elapsed / 1e9,
@@ -351,11 +454,19 @@ def main():
             "data": "synthetic (uniform noise projections generated on device; zero-initialised volume)",
             "config": {
                 "workload": w["name"] + (", 1 GPU" if world == 1 else ", %d z-slabs on %d GPUs" % (world, world)),
-                "projections_per_step": args.batch,
+                "projections_per_step": batch,
+                "projections_timed": timed_launches,
+                "whole_job": timed_launches == n_proj,
+                "angles_covered": {"distinct_projections": distinct, "of": n_proj,
+                                   "first_deg": 0.0, "last_deg": 360.0 * ((timed_launches - 1) % n_proj) / n_proj
+                                   if timed_launches < n_proj else 360.0 * (n_proj - 1) / n_proj},
                 "slab_per_gpu": [out_geo.dim_x, out_geo.dim_y, z_count],
                 "detector_row_band_rank0": [band_first, band_count],
                 "parallelism": "z-slab per GPU, no collective on the data path",
                 "backproject_kernel_ms": avg_ms,
+                "backproject_kernel_ms_min": min(kernel_ms) if kernel_ms else 0.0,
+                "backproject_kernel_ms_max": max(kernel_ms) if kernel_ms else 0.0,
+                "backproject_kernel_ms_by_octant": octants,
                 "backproject_GVox_per_s_per_gpu": voxels_rank / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
             },
             "roofline": {
@@ -367,22 +478,14 @@ def main():
                 "launches_timed": len(kernel_ms),
             },
         }
+        if octants:
+            worst = max(octants, key=lambda o: o["mean_ms"])
+            best = min(octants, key=lambda o: o["mean_ms"])
+            out["roofline"]["frac_worst_octant"] = algo_bytes / (worst["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["frac_best_octant"] = algo_bytes / (best["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if fused is not None:
             per_launch = voxels_rank * fb
-            out["fused_extension"] = {
-                "what": "the same per-projection copy + weight + filter, but one fused launch adds %d projections "
-                        "(paris_hip_backproject_batch; bit-identical volume); not the headline because the plugin boundary is one "
-                        "projection per call" % fb,
-                "value": voxels_all * fb * fused["steps"] / fused["seconds"] / 1e9,
-                "unit": "GVoxel-updates/s",
-                "kernel_ms_per_launch": fused["kernel_ms"],
-                "kernel_GVox_per_s_per_gpu": per_launch / (fused["kernel_ms"] * 1e-3) / 1e9 if fused["kernel_ms"] > 0 else 0.0,
-                "algorithmic_bytes_per_update": 8.0 / fb,
-                "projections_per_launch": fb,
-                "hbm_GBps": (8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col * fb) / (fused["kernel_ms"] * 1e-3) / 1e9
-                            if fused["kernel_ms"] > 0 else 0.0,
-                "bound": "vector ALU issue (HBM term divided by the batch size)",
-            }
+            out["fused_extension"] = fused_report(fused, fb, f16, voxels_rank, voxels_all, n_row, n_col, per_launch)
             if not f16:
                 out["deferred_boundary"] = {
                     "what": "the headline's step unchanged -- one paris_hip_backproject call per projection -- with "
@@ -392,6 +495,10 @@ def main():
                     "value": voxels_all * fused["deferred_projections"] / fused["deferred_seconds"] / 1e9,
                     "unit": "GVoxel-updates/s",
                 }
+        if gather is not None:
+            out["final_gather"] = gather
+        if dist is not None:
+            out["config"]["rank_placement"] = placement
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -26,3 +26,104 @@ def slab_of_task(info, task_id):
 def tasks_of_rank(info, rank, world_size):
     """Round-robin assignment of slab tasks to ranks; with num == world_size each rank owns exactly one slab."""
     return [t for t in range(info.num) if t % world_size == rank]
+
+
+# ---- rank placement and the job's one collective (bench.py --gpus N, tests/test_sharding_gloo.py) -------------------
+
+def device_of_rank(local_rank, n_visible, forced=-1):
+    """GPU index of a rank: `forced` when given (rehearsals), LOCAL_RANK when that many devices are visible, else
+    LOCAL_RANK modulo the visible count -- a launcher may hand every rank its own single visible device
+    (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES), then every rank's index is 0."""
+    if forced >= 0:
+        return int(forced)
+    if n_visible <= 0:
+        raise RuntimeError("no GPU visible to local rank %d" % local_rank)
+    return local_rank if local_rank < n_visible else local_rank % n_visible
+
+
+def gather_placement(dist, dev_index, props=None):
+    """All-gathers (host, visible-devices mask, device index, PCI bus id / uuid when the runtime exposes them) of every rank."""
+    import os
+    import socket
+    mine = {
+        "rank": dist.get_rank(), "host": socket.gethostname(), "device": int(dev_index),
+        "visible": os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES")
+                   or os.environ.get("CUDA_VISIBLE_DEVICES") or "",
+    }
+    for attr in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        v = getattr(props, attr, None) if props is not None else None
+        if v is not None:
+            mine[attr] = str(v)
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, mine)
+    return out
+
+
+def physical_key(entry):
+    """what identifies the physical GPU of a rank as far as the gathered record can tell"""
+    if "uuid" in entry:
+        return (entry["host"], "uuid", entry["uuid"])
+    if "pci_bus_id" in entry:
+        return (entry["host"], "pci", entry.get("pci_domain_id", ""), entry["pci_bus_id"], entry.get("pci_device_id", ""))
+    return (entry["host"], "index", entry["visible"], entry["device"])
+
+
+def check_placement(placement, exclusive=True):
+    """Raises when two ranks sit on the same physical GPU (exclusive=False: gloo rehearsals share one on purpose)."""
+    seen = {}
+    for e in placement:
+        k = physical_key(e)
+        if k in seen and exclusive:
+            raise RuntimeError("ranks %d and %d are both placed on GPU %r: one rank per GPU is required"
+                               % (seen[k], e["rank"], k))
+        seen.setdefault(k, e["rank"])
+    return len(seen)
+
+
+def slab_checksum(slab):
+    """(sum, sum of squares) of a slab in float64 -- torch tensor on any device, or a numpy array"""
+    import torch
+    t = slab if isinstance(slab, torch.Tensor) else torch.from_numpy(slab)
+    s = torch.sum(t, dtype=torch.float64)
+    q = torch.linalg.vector_norm(t.reshape(-1), ord=2, dtype=torch.float64) ** 2  # accumulates in float64, no fp64 copy
+    return torch.stack([s, q])
+
+
+def final_gather(dist, slab, info, rank, world, full=False, on_device=True, dst=0):
+    """The only collective of the job (BASELINE north star: "no RCCL collective needed beyond a final gather"; the
+    reference writes each slab from its own thread, src/sink.cpp:72-82). Always: all-gather of the per-slab checksums
+    (every rank learns the checksum of checksums). full=True: the slabs themselves are gathered on rank `dst` in task order
+    (slabs are padded to the largest slab for the collective; the last one carries the remainder, src/make_volume.cpp:32-34)
+    and the assembled volume's checksum is compared with the gathered checksums.
+    on_device: tensors stay on the GPU (nccl = RCCL); otherwise they go through host memory (gloo)."""
+    import torch
+    dev = slab.device if on_device else torch.device("cpu")
+    mine = slab_checksum(slab).to(dev)
+    sums = torch.empty(world * 2, dtype=torch.float64, device=dev)  # flat: the concatenated form every backend accepts
+    dist.all_gather_into_tensor(sums, mine)
+    sums_h = sums.cpu().reshape(world, 2)
+    res = {"checksums": [float(v) for v in sums_h[:, 0]], "checksum_of_checksums": float(sums_h[:, 0].sum()),
+           "sumsq": [float(v) for v in sums_h[:, 1]]}
+    if not full:
+        return res
+    counts = [slab_of_task(info, t)[1] for t in range(world)]
+    zmax = max(counts)
+    plane = slab.shape[1] * slab.shape[2]
+    send = slab if on_device else slab.cpu()
+    if send.shape[0] != zmax:
+        padded = torch.zeros((zmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        padded[:send.shape[0]] = send
+        send = padded
+    send = send.contiguous()
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst)
+    res["gathered_bytes"] = float(sum(counts) - counts[dst]) * plane * 4.0  # bytes that crossed a link into dst
+    if rank == dst:
+        ok = True
+        for t in range(world):
+            got = float(torch.sum(recv[t][:counts[t]], dtype=torch.float64))
+            want = res["checksums"][t]
+            ok = ok and abs(got - want) <= 1e-9 * max(1.0, abs(want))
+        res["gathered_matches_checksums"] = bool(ok)
+        res["volume"] = recv, counts  # slabs in task order (padded) and their true depths
+    return res

@@ -32,7 +32,16 @@ def test_single_gpu_line():
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches_timed"] == 3 * 8
+    # default batch: the timed steps are the whole job (360 projections of config 1 in 3 steps), the full circle
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches_timed"] == 360
+    cfg = d["config"]
+    assert cfg["projections_per_step"] == 120 and cfg["projections_timed"] == 360 and cfg["whole_job"] is True
+    assert cfg["angles_covered"]["distinct_projections"] == 360 and cfg["angles_covered"]["of"] == 360
+    octs = cfg["backproject_kernel_ms_by_octant"]
+    assert len(octs) == 8 and sum(o["launches"] for o in octs) == 360
+    assert all(o["min_ms"] <= o["mean_ms"] <= o["max_ms"] for o in octs)
+    fr = d["fused_extension"]["roofline"]
+    assert fr is None or (fr["bound"] == "valu_issue" and abs(fr["frac"] - fr["achieved"] / fr["peak"]) < 1e-12)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
 
@@ -50,3 +59,23 @@ def test_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["slab_per_gpu"] == [256, 256, 128]  # 256 slices split over two ranks
     assert "cpu_baseline" not in d                          # rank 0 at N = 1 only
+    fg = d["final_gather"]                                  # the job's one collective, here over gloo
+    assert fg["rccl_ranks_seen"] == 2 and fg["mode"] == "checksums" and len(fg["slab_checksums"]) == 2
+    assert abs(fg["checksum_of_checksums"] - sum(fg["slab_checksums"])) <= 1e-9 * max(1.0, abs(fg["checksum_of_checksums"]))
+    assert [e["rank"] for e in d["config"]["rank_placement"]] == [0, 1]
+
+
+def test_two_rank_rehearsal_gathers_slabs():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload",
+                        "c1", "--steps", "1", "--warmup", "0", "--batch", "4", "--dist-backend", "gloo", "--device", "0",
+                        "--fused-steps", "0", "--final-gather", "slabs"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json_line(r.stdout)
+    fg = d["final_gather"]
+    assert fg["mode"] == "slabs" and fg["gathered_matches_checksums"] is True
+    assert fg["gathered_bytes"] == 4.0 * 256 * 256 * 128 and d["config"]["whole_job"] is False

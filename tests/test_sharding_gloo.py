@@ -61,6 +61,77 @@ def _worker(rank, world, port, dim_z_override, result_path):
     dist.destroy_process_group()
 
 
+def _gather_worker(rank, world, port, result_path):
+    """bench.py's own final_gather / placement code (paris_amd.sharding) over gloo, slabs from the oracle"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle as O
+    from paris_amd import backend as B
+    from paris_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = (64, 48, 0.2, 0.25, 1.5, -0.75, 100, 200, 45)
+    det, odet = B.DetectorGeometry(*g), O.DetectorGeometry(*g)
+    vg = B.calculate_volume_geometry(det)
+    ovg = O.calculate_volume_geometry(odet)
+    info = sharding.make_subvolume_info(vg, world)
+    z_first, z_count = sharding.slab_of_task(info, rank)
+    slab = torch.from_numpy(O.reconstruct(odet, ovg, 3, v_dims=(z_count, vg.dim_y, vg.dim_x), v_offset=z_first))
+
+    placement = sharding.gather_placement(dist, sharding.device_of_rank(rank, 0, forced=0))
+    shared = sharding.check_placement(placement, exclusive=False)  # a rehearsal: all ranks on "device 0" of one host
+    try:
+        sharding.check_placement(placement, exclusive=True)
+        exclusive_raises = False
+    except RuntimeError:
+        exclusive_raises = True
+
+    light = sharding.final_gather(dist, slab, info, rank, world, full=False, on_device=False)
+    full = sharding.final_gather(dist, slab, info, rank, world, full=True, on_device=False)
+    if rank == 0:
+        want = O.reconstruct(odet, ovg, 3)
+        parts, counts = full["volume"]
+        got = np.concatenate([parts[t][:counts[t]].numpy() for t in range(world)])
+        sums_ok = all(abs(light["checksums"][t] - float(want[sharding.slab_of_task(info, t)[0]:][:counts[t]].sum(dtype=np.float64)))
+                      <= 1e-9 * max(1.0, abs(light["checksums"][t])) for t in range(world))
+        np.save(result_path, np.array([
+            float(np.array_equal(got, want)), float(sums_ok), float(full["gathered_matches_checksums"]),
+            float(abs(light["checksum_of_checksums"] - want.sum(dtype=np.float64)) <= 1e-9 * abs(want.sum(dtype=np.float64))),
+            float(shared), float(exclusive_raises), float(len(placement)),
+            float(full["gathered_bytes"] == 4.0 * vg.dim_x * vg.dim_y * (vg.dim_z - counts[0]))]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_final_gather_and_placement(tmp_path, world):
+    import torch.multiprocessing as mp
+    result = str(tmp_path / "g.npy")
+    mp.spawn(_gather_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+    same, sums_ok, matches, total_ok, shared, exclusive_raises, n, bytes_ok = np.load(result)
+    assert same == 1.0 and sums_ok == 1.0 and matches == 1.0 and total_ok == 1.0 and bytes_ok == 1.0
+    assert shared == 1.0 and exclusive_raises == 1.0 and n == world  # every rank reported, all on one (shared) device
+
+
+def test_device_of_rank():
+    sys.path.insert(0, ROOT)
+    from paris_amd import sharding
+    assert [sharding.device_of_rank(r, 8) for r in range(8)] == list(range(8))
+    assert [sharding.device_of_rank(r, 1) for r in range(8)] == [0] * 8  # one visible device per rank
+    assert sharding.device_of_rank(5, 4) == 1 and sharding.device_of_rank(3, 8, forced=0) == 0
+    with pytest.raises(RuntimeError):
+        sharding.device_of_rank(0, 0)
+    a = {"rank": 0, "host": "n0", "device": 0, "visible": "0"}
+    b = {"rank": 1, "host": "n0", "device": 0, "visible": "1"}
+    assert sharding.check_placement([a, b]) == 2                       # same index, different visible mask: two GPUs
+    with pytest.raises(RuntimeError):
+        sharding.check_placement([a, dict(a, rank=1)])
+    assert sharding.check_placement([dict(a, uuid="x"), dict(b, uuid="y")]) == 2
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_slab_sharding_matches_single_rank(tmp_path, world):
     import torch.multiprocessing as mp
