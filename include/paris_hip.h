@@ -142,6 +142,14 @@ int paris_hip_memset_volume(paris_hip_ctx* ctx, float* d_ptr, uint32_t dim_x, ui
 int paris_hip_make_subvolume_information(const paris_volume_geometry* vol_geo,
                                          const paris_detector_geometry* det_geo, int n_devices,
                                          paris_subvolume_info* out);
+/* Extension: the same rule for a driver that keeps `reserve_bytes` of its own buffers per device beside the slab (upload
+ * slots, half-precision copies, the deferral ring): a slab plus max(reserve_bytes, the reference's 10-projection allowance)
+ * must fit. hipErrorOutOfMemory when reserve_bytes alone does not fit a device. */
+int paris_hip_make_subvolume_information_reserving(const paris_volume_geometry* vol_geo,
+                                                   const paris_detector_geometry* det_geo, int n_devices,
+                                                   size_t reserve_bytes, paris_subvolume_info* out);
+/* Extension: free and total memory of a device handle (hipMemGetInfo), for sizing driver buffers before planning. */
+int paris_hip_device_memory(int device, size_t* free_bytes, size_t* total_bytes);
 
 /* ---- weighting: backend::weight (src/openmp/weighting.cpp:32-57, src/cuda/weighting.cu:62-73) ---- */
 /* p[t][s] *= d_sd / sqrt(d_sd^2 + h_s^2 + v_t^2), h_s = l_px_row/2 + s*l_px_row + h_min, v_t likewise.

@@ -18,6 +18,9 @@
 //     registers; per z step only v is recomputed (src/openmp/backprojection.cpp:130-133).
 #include "bp_device.h"
 
+#include <mutex>
+#include <utility>
+
 namespace
 {
     // Exhaustive check of div_by_constant for one divisor: all 2^32 bit patterns of x. The quotient is consumed
@@ -397,7 +400,49 @@ namespace
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     }
 
-    // Is div_by_constant exact for this divisor? Checked once per ctx and divisor on the GPU (about 2 ms).
+    // Is div_by_constant exact for this divisor? Checked once per process, device and divisor on the GPU (about 2 ms): the
+    // result is a property of the divisor, so it is cached process-wide (every ctx of every host thread shares it) and the
+    // check runs on a private blocking-free stream of its own -- never on the caller's stream, which may be capturing or may
+    // hold queued work the caller does not want to wait for. paris_hip_stage_filter pre-validates the detector's pixel pitches
+    // (they are known from det_geo long before the first backprojection), so the first paris_hip_backproject of a PARIS loop
+    // finds the answer cached and stays asynchronous.
+    std::mutex fastdiv_mutex;
+    std::map<std::pair<int, uint32_t>, bool> fastdiv_cache; // (device, divisor bits) -> exhaustive check result
+
+    int fastdiv_check_on_device(float c, bool* ok)
+    {
+        *ok = false;
+        hipStream_t s = nullptr;
+        unsigned long long* d_bad = nullptr;
+        unsigned long long* h_bad = nullptr;
+        hipError_t err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if(err == hipSuccess)
+            err = hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(*d_bad));
+        if(err == hipSuccess)
+            err = hipHostMalloc(reinterpret_cast<void**>(&h_bad), sizeof(*h_bad), hipHostMallocDefault);
+        if(err == hipSuccess)
+            err = hipMemsetAsync(d_bad, 0, sizeof(*d_bad), s);
+        if(err == hipSuccess)
+        {
+            *h_bad = ~0ull;
+            hipLaunchKernelGGL(fastdiv_validate_kernel, dim3(1u << 16), dim3(256), 0, s, c, 1.f / c, d_bad);
+            err = hipGetLastError();
+        }
+        if(err == hipSuccess)
+            err = hipMemcpyAsync(h_bad, d_bad, sizeof(*h_bad), hipMemcpyDeviceToHost, s);
+        if(err == hipSuccess)
+            err = hipStreamSynchronize(s);
+        if(err == hipSuccess)
+            *ok = *h_bad == 0ull;
+        if(h_bad != nullptr)
+            (void)hipHostFree(h_bad);
+        if(d_bad != nullptr)
+            (void)hipFree(d_bad);
+        if(s != nullptr)
+            (void)hipStreamDestroy(s);
+        return static_cast<int>(err);
+    }
+
     int fastdiv_is_exact(paris_hip_ctx* ctx, float c, bool* ok)
     {
         *ok = false;
@@ -406,22 +451,36 @@ namespace
         uint32_t key;
         static_assert(sizeof(key) == sizeof(c), "fp32");
         std::memcpy(&key, &c, sizeof(key));
-        auto it = ctx->fastdiv_exact.find(key);
+        auto it = ctx->fastdiv_exact.find(key); // per-ctx copy: no lock on the hot path
         if(it == ctx->fastdiv_exact.end())
         {
-            unsigned long long* d_bad = nullptr;
-            PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(*d_bad)));
-            PARIS_HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(*d_bad), ctx->stream));
-            hipLaunchKernelGGL(fastdiv_validate_kernel, dim3(1u << 16), dim3(256), 0, ctx->stream, c, 1.f / c, d_bad);
-            unsigned long long bad = ~0ull;
-            PARIS_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
-            PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
-            PARIS_HIP_TRY(hipFree(d_bad));
-            it = ctx->fastdiv_exact.emplace(key, bad == 0ull).first;
+            std::lock_guard<std::mutex> lock(fastdiv_mutex);
+            const auto pkey = std::make_pair(ctx->device, key);
+            auto pit = fastdiv_cache.find(pkey);
+            if(pit == fastdiv_cache.end())
+            {
+                bool exact = false;
+                if(int rc = fastdiv_check_on_device(c, &exact))
+                    return rc;
+                pit = fastdiv_cache.emplace(pkey, exact).first;
+            }
+            it = ctx->fastdiv_exact.emplace(key, pit->second).first;
         }
         *ok = it->second;
         return PARIS_HIP_SUCCESS;
     }
+}
+
+// stages.cpp (paris_hip_stage_filter): validates the fast division for the detector's pixel pitches ahead of the first
+// backprojection, so that call does not block
+int paris_hip_prevalidate_fast_division(paris_hip_ctx* ctx, float l_px_row, float l_px_col)
+{
+    if(ctx == nullptr || ctx->bp_fastdiv == 0)
+        return PARIS_HIP_SUCCESS;
+    bool ok = false;
+    if(int rc = fastdiv_is_exact(ctx, l_px_row, &ok))
+        return rc;
+    return fastdiv_is_exact(ctx, l_px_col, &ok);
 }
 
 // validates the arguments of one backprojection and derives the kernel parameters; *skip = true for an empty volume
@@ -577,6 +636,8 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
     }
     PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
     ++ctx->bp_launches;
+    if(int rc = paris_hip_note_projection_use(ctx, d_p))
+        return rc;
     return paris_hip_finish(ctx);
 }
 
@@ -659,6 +720,8 @@ static int defer_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitc
     char* slot = reinterpret_cast<char*>(ctx->defer_ring) + ctx->defer_pitch * p_dim_y * ctx->defer_count;
     PARIS_HIP_TRY(hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * sizeof(float), p_dim_y,
                                    hipMemcpyDeviceToDevice, ctx->stream));
+    if(int rc = paris_hip_note_projection_use(ctx, d_p)) // the snapshot copy is the last reader of the caller's buffer
+        return rc;
     ctx->defer_sin[ctx->defer_count] = sin_phi;
     ctx->defer_cos[ctx->defer_count] = cos_phi;
     if(++ctx->defer_count == ctx->defer_depth)
@@ -738,6 +801,8 @@ extern "C" int paris_hip_convert_projection_f16(paris_hip_ctx* ctx, const float*
     const dim3 grid((dim_x + 255u) / 256u, dim_y < 65535u ? dim_y : 65535u);
     hipLaunchKernelGGL(to_half_kernel, grid, dim3(256), 0, ctx->stream, d_src, static_cast<uint32_t>(src_pitch / sizeof(float)),
                        reinterpret_cast<_Float16*>(d_dst), static_cast<uint32_t>(dst_pitch / sizeof(uint16_t)), dim_x, dim_y);
+    if(int rc = paris_hip_note_projection_use(ctx, d_src))
+        return rc;
     return paris_hip_finish(ctx);
 }
 
@@ -779,6 +844,10 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(n_proj == 0)
         return paris_hip_finish(ctx);
+    // projection p of the batch lives at base + p * stride: consecutive projections must not overlap, and the kernel keeps
+    // the stride as a 32-bit pixel count
+    if(n_proj > 1 && (p_stride_bytes < p_pitch * static_cast<size_t>(p_dim_y) || p_stride_bytes / px > 0xffffffffull))
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
 
     // The cross-check variants take the sequence of single-projection launches that the fused kernel is defined to
     // equal, and so does a single projection: that is the tile kernel's case (memory bound, nothing to fuse).
@@ -824,6 +893,9 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
             break;
         fp.n_proj = n;
         fp.proj_stride = static_cast<uint32_t>(p_stride_bytes / px);
+        // fill_params decided the 4-pixel staging from the first projection's address: every later base must be as aligned
+        if(n > 1 && p_stride_bytes % (4u * px) != 0)
+            fp.g.stage_vec4 = 0u;
         for(uint32_t i = 0; i < n; ++i)
         {
             fp.sin_phi[i] = sin_phi[first + i];
@@ -834,6 +906,9 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         paris_hip_bp_launch_fused(&fp, fused_vx, tz16 ? 16 : 8, nt, fd, ctx->stream);
         PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
         ++ctx->bp_launches;
+        for(uint32_t i = 0; i < n && !ctx->upload_targets.empty(); ++i)
+            if(int rc = paris_hip_note_projection_use(ctx, p0 + static_cast<size_t>(i) * p_stride_bytes))
+                return rc;
     }
     return paris_hip_finish(ctx);
 }

@@ -170,7 +170,24 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
         (void)hipEventDestroy(kv.second.released);
         (void)hipHostFree(kv.second.ptr);
     }
-    ctx->defer_count = 0; // projections still deferred are dropped: their volume may be gone (flush or synchronize first)
+    if(ctx->defer_count != 0)
+    {
+        // Projections still deferred belong to key_v. Every library entry point that reads or frees a volume has flushed them
+        // already, so they are pending only if the caller touched the volume some other way (own kernel, torch tensor, plain
+        // hipFree). Run them if key_v is still a live device allocation -- the caller's later reads then see every projection --
+        // and drop them if it is gone (writing into freed memory would be worse than losing them).
+        hipPointerAttribute_t attr{};
+        const bool live = hipPointerGetAttributes(&attr, ctx->key_v) == hipSuccess && attr.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        if(live)
+        {
+            (void)paris_hip_flush_deferred(ctx);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+        ctx->defer_count = 0;
+    }
+    for(auto& kv : ctx->upload_targets)
+        (void)hipEventDestroy(kv.second.last_use);
     if(ctx->defer_ring != nullptr)
         (void)hipFree(ctx->defer_ring);
     if(ctx->stage_k != nullptr)
@@ -386,6 +403,7 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
         // a projection buffer: deferred backprojections hold their own snapshots, nothing pending refers to it
         const size_t bytes = proj->second;
         ctx->proj_allocs.erase(proj);
+        paris_hip_forget_upload_target(ctx, d_ptr);
         bool parked = false;
         if(int rc = pool_park(ctx, ctx->proj_pool, bytes, d_ptr, &parked))
             return rc;
@@ -409,9 +427,20 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
                 return rc;
         (void)hipGetLastError();
     }
+    paris_hip_forget_upload_target(ctx, d_ptr);
     PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
     PARIS_HIP_TRY(hipFree(d_ptr));
     return PARIS_HIP_SUCCESS;
+}
+
+void paris_hip_forget_upload_target(paris_hip_ctx* ctx, const void* d_p)
+{
+    auto it = ctx->upload_targets.find(d_p);
+    if(it != ctx->upload_targets.end())
+    {
+        (void)hipEventDestroy(it->second.last_use);
+        ctx->upload_targets.erase(it);
+    }
 }
 
 extern "C" int paris_hip_malloc_host(paris_hip_ctx* ctx, size_t bytes, void** h_ptr)
@@ -485,6 +514,19 @@ extern "C" int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, siz
             ctx->upload_events.push_back(e);
         }
     }
+    // Write-after-read on slot reuse: kernels already queued on the compute stream may still read d_dst. The upload waits for
+    // the LAST library call that touched this very buffer (paris_hip_note_projection_use records it), not for everything queued:
+    // work on other buffers keeps overlapping the transfer. The first upload into a buffer registers it.
+    auto target = ctx->upload_targets.find(d_dst);
+    if(target == ctx->upload_targets.end())
+    {
+        paris_hip_ctx::upload_target t;
+        PARIS_HIP_TRY(hipEventCreateWithFlags(&t.last_use, hipEventDisableTiming));
+        target = ctx->upload_targets.emplace(d_dst, t).first;
+    }
+    else if(target->second.used)
+        PARIS_HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, target->second.last_use, 0));
+    target->second.bytes = std::max(target->second.bytes, d_pitch * dim_y);
     hipEvent_t done = ctx->upload_events[ctx->uploads++ % ctx->upload_events.size()];
     PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
                                    hipMemcpyHostToDevice, ctx->upload_stream));
@@ -538,9 +580,9 @@ extern "C" int paris_hip_memcpy_volume_d2h(paris_hip_ctx* ctx, float* h_dst, con
 // src/cuda/subvolume_information.cpp:63-118: start with one slab per device and double the slab count until
 // (volume + 10 projections) / devices fits the free memory of every device. 64-bit sizes; the
 // reference's trial allocation is replaced by the free-memory test alone with a 5 % safety margin.
-extern "C" int paris_hip_make_subvolume_information(const paris_volume_geometry* vol_geo,
-                                                    const paris_detector_geometry* det_geo, int n_devices,
-                                                    paris_subvolume_info* out)
+extern "C" int paris_hip_make_subvolume_information_reserving(const paris_volume_geometry* vol_geo,
+                                                              const paris_detector_geometry* det_geo, int n_devices,
+                                                              size_t reserve_bytes, paris_subvolume_info* out)
 {
     if(vol_geo == nullptr || det_geo == nullptr || out == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
@@ -554,7 +596,11 @@ extern "C" int paris_hip_make_subvolume_information(const paris_volume_geometry*
 
     const size_t vol = static_cast<size_t>(vol_geo->dim_x) * vol_geo->dim_y * vol_geo->dim_z * sizeof(float); // :53
     const size_t proj = static_cast<size_t>(det_geo->n_row) * det_geo->n_col * sizeof(float);                // :54
-    size_t mem_needed = (vol + 10u * proj) / static_cast<size_t>(devices);                                     // :73-77
+    // :73-77 charges every device (volume + 10 projections) / devices. A driver that keeps more than that beside the slab
+    // (upload slots, half-precision copies, the deferral ring) passes its per-device total as reserve_bytes: unlike the
+    // slab it does not shrink when the slab count doubles.
+    const size_t vol_dev = vol / static_cast<size_t>(devices);
+    const size_t fixed = std::max(10u * proj / static_cast<size_t>(devices), reserve_bytes);
     uint32_t vols_needed = static_cast<uint32_t>(devices);                                                     // :79
 
     int current = 0;
@@ -568,12 +614,13 @@ extern "C" int paris_hip_make_subvolume_information(const paris_volume_geometry*
         size_t mem_free = 0, mem_total = 0;
         PARIS_HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
         mem_free -= mem_free / 20u;
-        size_t mem_dev = mem_needed;
-        while(mem_dev >= mem_free && vols_needed < vol_geo->dim_z) // :91-95
+        if(reserve_bytes != 0 && reserve_bytes >= mem_free)
         {
-            mem_dev /= 2;
-            vols_needed *= 2;
+            (void)hipSetDevice(current);
+            return static_cast<int>(hipErrorOutOfMemory); // the driver's own buffers do not fit: it must shrink them first
         }
+        while(vol_dev / (vols_needed / static_cast<uint32_t>(devices)) + fixed >= mem_free && vols_needed < vol_geo->dim_z) // :91-95
+            vols_needed *= 2;
     }
     (void)hipSetDevice(current);
     if(vols_needed > vol_geo->dim_z)
@@ -584,6 +631,33 @@ extern "C" int paris_hip_make_subvolume_information(const paris_volume_geometry*
     out->geo.dim_z = vol_geo->dim_z / vols_needed;
     out->geo.remainder = vol_geo->dim_z % vols_needed;
     out->num = static_cast<int>(vols_needed);
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_make_subvolume_information(const paris_volume_geometry* vol_geo,
+                                                    const paris_detector_geometry* det_geo, int n_devices,
+                                                    paris_subvolume_info* out)
+{
+    return paris_hip_make_subvolume_information_reserving(vol_geo, det_geo, n_devices, 0, out);
+}
+
+extern "C" int paris_hip_device_memory(int device, size_t* free_bytes, size_t* total_bytes)
+{
+    if(free_bytes == nullptr || total_bytes == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    int physical = 0;
+    if(int rc = physical_device_count(&physical))
+        return rc;
+    if(physical == 0)
+        return PARIS_HIP_ERROR_NO_DEVICE;
+    if(device < 0)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    int current = 0;
+    (void)hipGetDevice(&current);
+    PARIS_HIP_TRY(hipSetDevice(device % physical));
+    const hipError_t err = hipMemGetInfo(free_bytes, total_bytes);
+    (void)hipSetDevice(current);
+    PARIS_HIP_TRY(err);
     return PARIS_HIP_SUCCESS;
 }
 

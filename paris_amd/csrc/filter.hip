@@ -527,10 +527,14 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
         }
         if(rc != PARIS_HIP_SUCCESS)
             return rc;
+        if(int rc2 = paris_hip_note_projection_use(ctx, d_p))
+            return rc2;
         return paris_hip_finish(ctx);
     }
     hipLaunchKernelGGL(apply_filter_kernel, dim3((dim_y + 1u) / 2u), dim3(threads_for(filter_size)),
                        filter_size * sizeof(float2), ctx->stream, d_p, pitch_f, dim_x, dim_y, d_k, plan->d_twiddle, log2n);
+    if(int rc = paris_hip_note_projection_use(ctx, d_p))
+        return rc;
     return paris_hip_finish(ctx);
 }
 

@@ -55,6 +55,16 @@ struct paris_hip_ctx
     hipStream_t upload_stream = nullptr;
     std::vector<hipEvent_t> upload_events;
     uint64_t uploads = 0;
+    // device buffers that have been the destination of paris_hip_upload_projection: the event marks the last library call
+    // enqueued on the compute stream that reads or writes the buffer, so the next upload into it (slot reuse) waits for
+    // exactly that work and nothing else. Buffers never uploaded into this way are not tracked (no cost for other callers).
+    struct upload_target
+    {
+        hipEvent_t last_use = nullptr;
+        bool used = false;
+        size_t bytes = 0; // extent of the buffer as uploaded (pitch x rows): stage calls on a row band pass interior pointers
+    };
+    std::map<const void*, upload_target> upload_targets;
     // K cached by paris_hip_stage_filter (reference: thread_local static in src/filtering.cpp:42)
     float* stage_k = nullptr;
     uint32_t stage_k_size = 0;
@@ -107,6 +117,24 @@ inline int paris_hip_finish(paris_hip_ctx* ctx)
     return PARIS_HIP_SUCCESS;
 }
 
+// called by every stage entry point after it has enqueued work that reads or writes the projection buffer d_p
+inline int paris_hip_note_projection_use(paris_hip_ctx* ctx, const void* d_p)
+{
+    if(ctx->upload_targets.empty())
+        return PARIS_HIP_SUCCESS;
+    auto it = ctx->upload_targets.upper_bound(d_p); // the registered buffer that contains d_p, if any
+    if(it == ctx->upload_targets.begin())
+        return PARIS_HIP_SUCCESS;
+    --it;
+    if(static_cast<const char*>(d_p) >= static_cast<const char*>(it->first) + it->second.bytes)
+        return PARIS_HIP_SUCCESS;
+    PARIS_HIP_TRY(hipEventRecord(it->second.last_use, ctx->stream));
+    it->second.used = true;
+    return PARIS_HIP_SUCCESS;
+}
+
+void paris_hip_forget_upload_target(paris_hip_ctx* ctx, const void* d_p);
+
 inline int paris_hip_bind(paris_hip_ctx* ctx)
 {
     if(ctx == nullptr)
@@ -120,5 +148,9 @@ int paris_hip_get_plan(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_plan** out)
 // backproject.hip: runs the projections pending in the deferral ring (no-op when there are none). Called by every entry
 // point that observes or changes a volume, completes work, or changes how backprojection runs.
 int paris_hip_flush_deferred(paris_hip_ctx* ctx);
+
+// backproject.hip: exhaustive validation of the fast division by the detector's pixel pitches, ahead of the first
+// backprojection (cached per process and device; a no-op once known or when the fast division is switched off)
+int paris_hip_prevalidate_fast_division(paris_hip_ctx* ctx, float l_px_row, float l_px_col);
 
 #endif

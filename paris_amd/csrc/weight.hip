@@ -44,6 +44,8 @@ extern "C" int paris_hip_weight_rows(paris_hip_ctx* ctx, float* d_p, size_t pitc
     const dim3 grid((dim_x + 255u) / 256u, row_count < 65535u ? row_count : 65535u);
     hipLaunchKernelGGL(weight_kernel, grid, dim3(256), 0, ctx->stream, d_p, static_cast<uint32_t>(pitch / sizeof(float)),
                        dim_x, row_first, row_first + row_count, h_min, v_min, d_sd, l_px_row, l_px_col);
+    if(int rc = paris_hip_note_projection_use(ctx, d_p))
+        return rc;
     return paris_hip_finish(ctx);
 }
 

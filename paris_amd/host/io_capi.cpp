@@ -2,7 +2,9 @@
 // can exercise it through ctypes. No GPU code in here; built as paris_amd/lib/libparis_io.so.
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "paris/ddbvf.h"
@@ -136,6 +138,59 @@ int paris_io_stream_scan(const char* dir, int enable_angles, const char* angle_f
         }
         *n_frames = n;
         *n_skipped = static_cast<uint32_t>(src.skipped_files().size());
+        return 0;
+    }
+    catch(const std::exception&) { return 1; }
+}
+
+// shared_frames under `n_threads` consumers: thread i reads rows [row_first[i], row_first[i] + row_count[i]) of every frame into
+// data + i * cap * dim_x * dim_y (caller-filled with a sentinel); thread i sleeps delay_us[i] microseconds per frame, so a
+// slow consumer falls out of the ring (capacity) and takes its own fallback stream. counters: produced, served, reread.
+int paris_io_shared_scan(const char* dir, int enable_angles, const char* angle_file, uint16_t quality, uint32_t dim_x, uint32_t dim_y,
+                         uint32_t n_threads, const uint32_t* row_first, const uint32_t* row_count, const uint32_t* delay_us, uint32_t capacity,
+                         uint32_t cap, uint32_t* n_frames, uint32_t* idx_out, float* phi_out, float* data, uint64_t* counters)
+{
+    try
+    {
+        paris::shared_frames shared{dir, enable_angles != 0, angle_file ? angle_file : "", quality, dim_x, dim_y, capacity};
+        auto failed = std::vector<int>(n_threads, 0);
+        auto workers = std::vector<std::thread>{};
+        const auto frame = static_cast<size_t>(dim_x) * dim_y;
+        for(uint32_t i = 0; i < n_threads; ++i)
+            workers.emplace_back([&, i] {
+                try
+                {
+                    auto cur = paris::shared_frames::cursor{};
+                    auto scratch = std::vector<float>(frame);
+                    uint32_t n = 0;
+                    for(;;)
+                    {
+                        float* dst = n < cap ? data + (static_cast<size_t>(i) * cap + n) * frame : scratch.data();
+                        const auto info = shared.next(cur, dst, dim_x, dim_y, row_first[i], row_count[i]);
+                        if(!info.valid())
+                            break;
+                        if(n < cap)
+                        {
+                            idx_out[static_cast<size_t>(i) * cap + n] = info.idx;
+                            phi_out[static_cast<size_t>(i) * cap + n] = info.phi;
+                        }
+                        ++n;
+                        if(delay_us[i])
+                            std::this_thread::sleep_for(std::chrono::microseconds(delay_us[i]));
+                    }
+                    n_frames[i] = n;
+                }
+                catch(const std::exception&) { failed[i] = 1; }
+            });
+        for(auto& w : workers)
+            w.join();
+        for(int f : failed)
+            if(f)
+                return 1;
+        const auto st = shared.stats();
+        counters[0] = st.produced;
+        counters[1] = st.served;
+        counters[2] = st.reread;
         return 0;
     }
     catch(const std::exception&) { return 1; }

@@ -66,6 +66,8 @@ namespace paris
                 throw std::runtime_error{"ddbvf::write(): Starting position out of bounds"};
             if(dim_x != h->dim_x || dim_y != h->dim_y || dim_z_slab > h->dim_z) // :134-135
                 throw std::runtime_error{"ddbvf::write(): Attempting to save volume to file with wrong dimensions"};
+            if(dim_z_slab > h->dim_z - first) // the reference checks the two above only: a slab must also end inside the volume
+                throw std::runtime_error{"ddbvf::write(): Slab extends past the end of the volume"};
             const auto slice = static_cast<std::uint64_t>(dim_x) * dim_y * sizeof(float);
             const auto pos = static_cast<std::uint64_t>(first_pos) + slice * first;
             // positioned writes on the descriptor: no shared stream position, so slabs of different device threads can be
@@ -84,6 +86,8 @@ namespace paris
                         continue;
                     throw std::system_error{errno, std::generic_category(), "ddbvf::write()"};
                 }
+                if(done == 0) // no progress and no error (a full device can do this): never spin on it
+                    throw std::runtime_error{"ddbvf::write(): pwrite made no progress"};
                 bytes += done;
                 at += static_cast<std::uint64_t>(done);
                 left -= static_cast<std::uint64_t>(done);

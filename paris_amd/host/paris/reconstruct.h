@@ -22,9 +22,12 @@
 #include <cstdint>
 #include <cstring>
 #include <future>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "sink.h"
@@ -100,6 +103,64 @@ namespace paris
         std::mutex m_;
     };
 
+    // One read-once frame source (source.h: shared_frames) per pass of the task queue over the devices: tasks
+    // [p * n_dev, (p + 1) * n_dev) are popped at about the same time by the n_dev device threads and all need every frame,
+    // so the first thread to reach a frame reads it and the others copy their detector band from memory. A thread that
+    // arrives after the others have finished the pass gets a fresh source (= its own read of the files, as before).
+    class frame_pool
+    {
+    public:
+        frame_pool(int n_dev, std::uint32_t n_row, std::uint32_t n_col) : n_dev_{n_dev < 1 ? 1 : n_dev}, n_row_{n_row}, n_col_{n_col} {}
+
+        auto get(const struct task& t) -> std::shared_ptr<shared_frames>;
+
+        struct totals
+        {
+            std::uint64_t produced = 0, served = 0, reread = 0;
+        };
+        auto stats() -> totals
+        {
+            std::lock_guard<std::mutex> lock{m_};
+            auto sum = done_;
+            for(auto& kv : live_)
+                if(auto s = kv.second.lock())
+                {
+                    const auto c = s->stats();
+                    sum.produced += c.produced;
+                    sum.served += c.served;
+                    sum.reread += c.reread;
+                }
+            return sum;
+        }
+        auto skipped_files() -> std::vector<std::string>
+        {
+            std::lock_guard<std::mutex> lock{m_};
+            return skipped_;
+        }
+        // called by the last user of a pass's source (shared_ptr deleter)
+        void retire(shared_frames* s)
+        {
+            {
+                std::lock_guard<std::mutex> lock{m_};
+                const auto c = s->stats();
+                done_.produced += c.produced;
+                done_.served += c.served;
+                done_.reread += c.reread;
+                if(skipped_.empty())
+                    skipped_ = s->skipped_files();
+            }
+            delete s;
+        }
+
+    private:
+        int n_dev_;
+        std::uint32_t n_row_, n_col_;
+        std::mutex m_;
+        std::map<std::uint32_t, std::weak_ptr<shared_frames>> live_;
+        totals done_;
+        std::vector<std::string> skipped_;
+    };
+
     struct device_report
     {
         int device = 0;
@@ -108,6 +169,22 @@ namespace paris
         double source_s = 0, enqueue_s = 0, drain_s = 0, save_s = 0;
         std::vector<std::string> skipped;
     };
+
+    inline auto frame_pool::get(const task& t) -> std::shared_ptr<shared_frames>
+    {
+        const auto pass = t.id / static_cast<std::uint32_t>(n_dev_);
+        std::lock_guard<std::mutex> lock{m_};
+        auto& slot = live_[pass];
+        if(auto s = slot.lock())
+            return s;
+        // ring depth: how far the device threads may drift apart before the slower one re-reads; at most ~1 GiB of frames
+        const auto frame_bytes = static_cast<std::size_t>(n_row_) * n_col_ * sizeof(float);
+        const auto capacity = std::max<std::size_t>(4, std::min<std::size_t>(32, (std::size_t{1} << 30) / std::max<std::size_t>(1, frame_bytes)));
+        auto s = std::shared_ptr<shared_frames>{new shared_frames{t.input_path, t.enable_angles, t.angle_path, t.quality, n_row_, n_col_, capacity},
+                                                [this](shared_frames* p) { retire(p); }};
+        slot = s;
+        return s;
+    }
 
     namespace detail
     {
@@ -118,10 +195,45 @@ namespace paris
         }
         using clock = std::chrono::steady_clock;
         inline double since(clock::time_point t) { return std::chrono::duration<double>(clock::now() - t).count(); }
+
+        // frames per group and groups, as reconstruct() lays its slots out
+        inline auto slot_shape(const program_options& po) -> std::pair<std::uint32_t, std::uint32_t>
+        {
+            const std::uint32_t batch = po.batch < 1 ? 1u : static_cast<std::uint32_t>(po.batch > 32 ? 32 : po.batch);
+            const std::uint32_t groups = batch == 1u ? static_cast<std::uint32_t>(po.slots < 1 ? 1 : po.slots) : 2u;
+            return {batch, groups};
+        }
+
+        // device memory reconstruct() keeps per device beside the slab: every slot's fp32 frame (rows padded to 256 B), its
+        // half copy with --f16, and two drain chunks' worth of slack for the runtime's own staging
+        inline auto driver_bytes(const program_options& po) -> std::size_t
+        {
+            const auto shape = slot_shape(po);
+            const auto slots = static_cast<std::size_t>(shape.first) * shape.second;
+            const auto row = (static_cast<std::size_t>(po.det_geo.n_row) * sizeof(float) + 255u) / 256u * 256u;
+            const auto half_row = (static_cast<std::size_t>(po.det_geo.n_row) * 2u + 255u) / 256u * 256u;
+            return slots * po.det_geo.n_col * (row + (po.f16 ? half_row : 0u)) + 2u * po.drain_chunk_bytes;
+        }
+
+        // Large detectors: halve the frames per group until the driver's buffers take at most a quarter of the smallest
+        // device's free memory (8192^2 frames: 32 slots would be 8 GiB of device frames plus as much pinned host memory)
+        inline auto fit_batch(program_options po, int n_dev) -> program_options
+        {
+            std::size_t smallest = ~std::size_t{0};
+            for(int d = 0; d < n_dev; ++d)
+            {
+                std::size_t free_b = 0, total_b = 0;
+                rt(paris_hip_device_memory(d, &free_b, &total_b), "device memory");
+                smallest = std::min(smallest, free_b);
+            }
+            while(po.batch > 1 && driver_bytes(po) > smallest / 4u)
+                po.batch /= 2;
+            return po;
+        }
     }
 
     // src/main.cpp:79-109, pipelined
-    inline auto reconstruct(task_queue& queue, int device, sink& out, const program_options& po) -> device_report
+    inline auto reconstruct(task_queue& queue, int device, sink& out, const program_options& po, frame_pool* pool = nullptr) -> device_report
     {
         using namespace detail;
         auto rep = device_report{};
@@ -133,8 +245,7 @@ namespace paris
         // then backprojected with ONE fused launch (paris_hip_backproject_batch[_f16]: bit-identical to the sequence, the slab
         // is read and written once per group). While the GPU works on one group the host fills the next. batch = 1 is the
         // reference's one launch per projection with `slots` single-frame groups.
-        const std::uint32_t batch = po.batch < 1 ? 1u : static_cast<std::uint32_t>(po.batch > 32 ? 32 : po.batch);
-        const std::uint32_t groups = batch == 1u ? static_cast<std::uint32_t>(po.slots < 1 ? 1 : po.slots) : 2u;
+        const std::uint32_t batch = slot_shape(po).first, groups = slot_shape(po).second;
         rt(paris_hip_set_filter_window(ctx, po.window), "filter window");
         const int slots = static_cast<int>(batch * groups);
         const auto n_row = po.det_geo.n_row, n_col = po.det_geo.n_col;
@@ -236,7 +347,12 @@ namespace paris
                 const auto row_bytes = static_cast<std::size_t>(n_row) * sizeof(float);
 
                 auto t0 = clock::now();
-                frame_stream src{t.input_path, t.enable_angles, t.angle_path, t.quality}; // :93 (index restarts per task)
+                // :93 (index restarts per task). Several devices: the frames come from the pass's read-once source
+                auto shared = pool != nullptr ? pool->get(t) : std::shared_ptr<shared_frames>{};
+                auto cur = shared_frames::cursor{};
+                auto own = std::unique_ptr<frame_stream>{};
+                if(!shared)
+                    own.reset(new frame_stream{t.input_path, t.enable_angles, t.angle_path, t.quality});
                 rep.source_s += since(t0);
                 std::uint32_t group = 0, filled = 0; // frames of the current group already enqueued
                 auto sines = std::vector<float>(batch), cosines = std::vector<float>(batch);
@@ -269,7 +385,8 @@ namespace paris
                     // f4: only the detector rows this slab can read are converted, uploaded, weighted and filtered; the
                     // buffers keep their full size, rows outside the band are never read for a voxel of the slab
                     t0 = clock::now();
-                    const auto p = src.next(h_buf[slot], n_row, n_col, band_first, band_count); // :100, straight into pinned memory
+                    const auto p = shared ? shared->next(cur, h_buf[slot], n_row, n_col, band_first, band_count)
+                                          : own->next(h_buf[slot], n_row, n_col, band_first, band_count); // :100, straight into pinned memory
                     rep.source_s += since(t0);
                     if(!p.valid())
                         break;
@@ -297,7 +414,7 @@ namespace paris
                     ++rep.projections;
                 }
                 flush(); // the last, possibly partial group
-                for(const auto& s : src.skipped_files())
+                for(const auto& s : (shared ? cur.skipped_files() : own->skipped_files())) // the shared source's list: run_report
                     rep.skipped.push_back(s);
 
                 // src/sink.cpp:76-82 in chunks of whole slices: copy chunk k+1 down while chunk k goes to the file
@@ -342,13 +459,17 @@ namespace paris
         volume_geometry vol_geo{}, roi_geo{};
         subvolume_info info{};
         std::vector<device_report> devices;
+        std::uint64_t frames_read = 0, frames_shared = 0; // several devices: frames converted from the files / copied from the shared source
+        std::vector<std::string> skipped;                  // several devices: invalid files skipped by the shared source
+        int batch = 0; // frames per fused launch actually used (program_options::batch, halved until the slots fit the devices)
         double wall_s = 0;
         std::string output_file;
     };
 
     // src/main.cpp:120-178
-    inline auto run(const program_options& po) -> run_report
+    inline auto run(const program_options& requested) -> run_report
     {
+        auto po = requested; // batch may shrink to fit the devices' memory (detail::fit_batch)
         auto r = run_report{};
         const auto start = detail::clock::now();
         r.vol_geo = calculate_volume_geometry(po.det_geo); // :122
@@ -362,6 +483,8 @@ namespace paris
             throw stage_construction_error{"no HIP device"};
         if(po.devices > 0 && po.devices < n_dev)
             n_dev = po.devices;
+        po = detail::fit_batch(po, n_dev);
+        r.batch = po.batch;
 
         if(po.slabs > 0) // fixed split (src/cuda/subvolume_information.cpp:112-116 with a given count)
         {
@@ -369,8 +492,9 @@ namespace paris
             r.info.num = static_cast<int>(num);
             r.info.geo = {r.roi_geo.dim_x, r.roi_geo.dim_y, r.roi_geo.dim_z / num, r.roi_geo.dim_z % num};
         }
-        else
-            detail::rt(paris_hip_make_subvolume_information(&r.roi_geo, &po.det_geo, n_dev, &r.info), "make_subvolume_information()"); // :137
+        else // :137, with the driver's own per-device buffers charged next to the slab
+            detail::rt(paris_hip_make_subvolume_information_reserving(&r.roi_geo, &po.det_geo, n_dev, detail::driver_bytes(po), &r.info),
+                       "make_subvolume_information()");
 
         task_queue queue{make_tasks(po, r.vol_geo, r.info)}; // :140-141
         sink out{po.output_path, po.prefix, r.roi_geo};           // :154
@@ -378,11 +502,16 @@ namespace paris
 
         if(n_dev > 1) // :157-167
         {
+            frame_pool pool{n_dev, po.det_geo.n_row, po.det_geo.n_col}; // every HIS frame is read once per pass, not once per device
             auto futures = std::vector<std::future<device_report>>{};
             for(int d = 0; d < n_dev; ++d)
-                futures.emplace_back(std::async(std::launch::async, [&queue, &out, &po, d] { return reconstruct(queue, d, out, po); }));
+                futures.emplace_back(std::async(std::launch::async, [&queue, &out, &po, &pool, d] { return reconstruct(queue, d, out, po, &pool); }));
             for(auto& f : futures)
                 r.devices.push_back(f.get());
+            const auto st = pool.stats();
+            r.frames_read = st.produced + st.reread;
+            r.frames_shared = st.served;
+            r.skipped = pool.skipped_files();
         }
         else
             r.devices.push_back(reconstruct(queue, 0, out, po)); // :169

@@ -8,11 +8,15 @@
 
 #include <algorithm>
 #include <cctype>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <fstream>
 #include <iterator>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -248,6 +252,183 @@ namespace paris
         std::vector<float> angles_;
         std::uint16_t quality_;
         std::uint32_t counter_ = 0;
+    };
+
+    // Read-once frame source shared by the device threads of one run. Every device needs every projection for its slab;
+    // the reference lets each device thread read the whole set again (src/main.cpp:93: a source per task). Here the
+    // thread that first asks for the k-th kept frame reads and converts it, once, into a buffer of a small ring; the
+    // other threads copy the rows they need (their slab's detector band) from that buffer. Correctness never depends on
+    // the ring: a consumer whose frame has already been recycled (it lags more than `capacity` frames behind, or it starts
+    // a later task) falls back to a frame_stream of its own, exactly today's behaviour. Frames, order, indices, angles and
+    // skipped files are frame_stream's.
+    class shared_frames
+    {
+    public:
+        struct counters
+        {
+            std::uint64_t produced = 0; // frames read from the files by this object (each at most once)
+            std::uint64_t served = 0;   // next() calls answered from the ring
+            std::uint64_t reread = 0;   // next() calls answered by a consumer's own fallback stream
+        };
+
+        // per consumer and task: where it is in the sequence, and its fallback stream once it has needed one
+        class cursor
+        {
+            friend class shared_frames;
+            std::uint64_t next_ = 0;
+            std::unique_ptr<frame_stream> own_;
+            std::uint64_t own_pos_ = 0;
+        public:
+            auto skipped_files() const -> std::vector<std::string> { return own_ ? own_->skipped_files() : std::vector<std::string>{}; }
+        };
+
+        shared_frames(const std::string& proj_dir, bool enable_angles, const std::string& angle_file, std::uint16_t quality,
+                      std::uint32_t dim_x, std::uint32_t dim_y, std::size_t capacity = 32)
+        : dir_{proj_dir}, enable_angles_{enable_angles}, angle_file_{angle_file}, quality_{quality}, dim_x_{dim_x}, dim_y_{dim_y},
+          stream_{proj_dir, enable_angles, angle_file, quality}, ring_(capacity == 0 ? 1 : capacity)
+        {}
+
+        // frame_stream::next for the consumer behind `c`
+        auto next(cursor& c, float* dst, std::uint32_t dim_x, std::uint32_t dim_y, std::uint32_t row_first, std::uint32_t row_count) -> frame_info
+        {
+            if(dim_x != dim_x_ || dim_y != dim_y_)
+                throw std::runtime_error{"shared_frames::next(): frame size differs from the one the cache was built for"};
+            const auto k = c.next_++;
+            if(c.own_) // once behind, stay on the private stream: it is already positioned
+                return from_own(c, k, dst, row_first, row_count);
+            std::shared_ptr<const entry> e;
+            {
+                std::unique_lock<std::mutex> lock{m_};
+                for(;;)
+                {
+                    if(ended_ && k >= end_)
+                        return frame_info{};
+                    if(k < produced_)
+                    {
+                        const auto& slot = ring_[k % ring_.size()];
+                        if(slot && slot->ordinal == k)
+                        {
+                            e = slot;
+                            ++stats_.served;
+                        }
+                        break; // recycled: e stays empty
+                    }
+                    if(!producing_ && k == produced_)
+                    {
+                        producing_ = true;
+                        lock.unlock();
+                        auto fresh = produce(k);
+                        lock.lock();
+                        producing_ = false;
+                        if(fresh)
+                        {
+                            ring_[k % ring_.size()] = fresh;
+                            ++produced_;
+                            ++stats_.produced;
+                        }
+                        else
+                        {
+                            ended_ = true;
+                            end_ = k;
+                        }
+                        cv_.notify_all();
+                        continue;
+                    }
+                    cv_.wait(lock); // another thread is reading frame produced_ (this one, or one before it)
+                }
+            }
+            if(!e)
+                return from_own(c, k, dst, row_first, row_count);
+            if(e->info.dim_x == dim_x && e->info.dim_y == dim_y && row_count != 0)
+                std::memcpy(dst + static_cast<std::size_t>(row_first) * dim_x, e->pixels.data() + static_cast<std::size_t>(row_first) * dim_x,
+                            static_cast<std::size_t>(row_count) * dim_x * sizeof(float));
+            return e->info;
+        }
+
+        auto skipped_files() const -> std::vector<std::string>
+        {
+            std::lock_guard<std::mutex> lock{m_};
+            return stream_.skipped_files();
+        }
+
+        auto stats() const -> counters
+        {
+            std::lock_guard<std::mutex> lock{m_};
+            return stats_;
+        }
+
+    private:
+        struct entry
+        {
+            std::uint64_t ordinal = 0;
+            frame_info info{};
+            std::vector<float> pixels; // the whole frame (consumers want different bands)
+        };
+
+        // reads the next kept frame of the shared stream; only ever called by one thread at a time (producing_)
+        auto produce(std::uint64_t k) -> std::shared_ptr<const entry>
+        {
+            // frame buffers are recycled: the deleter of an entry hands its pixel vector back (a fresh 16 MiB vector per
+            // frame would cost a page-faulting zero fill each time)
+            auto* raw = new entry;
+            {
+                std::lock_guard<std::mutex> lock{spare_m_};
+                if(!spare_.empty())
+                {
+                    raw->pixels = std::move(spare_.back());
+                    spare_.pop_back();
+                }
+            }
+            auto e = std::shared_ptr<entry>{raw, [this](entry* d) {
+                {
+                    std::lock_guard<std::mutex> lock{spare_m_};
+                    if(spare_.size() < ring_.size())
+                        spare_.push_back(std::move(d->pixels));
+                }
+                delete d;
+            }};
+            e->ordinal = k;
+            e->pixels.resize(static_cast<std::size_t>(dim_x_) * dim_y_);
+            e->info = stream_.next(e->pixels.data(), dim_x_, dim_y_, 0, dim_y_);
+            if(!e->info.valid())
+                return nullptr;
+            return e;
+        }
+
+        auto from_own(cursor& c, std::uint64_t k, float* dst, std::uint32_t row_first, std::uint32_t row_count) -> frame_info
+        {
+            if(!c.own_)
+            {
+                c.own_.reset(new frame_stream{dir_, enable_angles_, angle_file_, quality_});
+                c.own_pos_ = 0;
+            }
+            for(; c.own_pos_ < k; ++c.own_pos_) // seek: kept frames before k are stepped over without conversion
+                if(!c.own_->next(dst, dim_x_, dim_y_, 0, 0).valid())
+                    return frame_info{};
+            ++c.own_pos_;
+            const auto info = c.own_->next(dst, dim_x_, dim_y_, row_first, row_count);
+            if(info.valid())
+            {
+                std::lock_guard<std::mutex> lock{m_};
+                ++stats_.reread;
+            }
+            return info;
+        }
+
+        std::string dir_;
+        bool enable_angles_;
+        std::string angle_file_;
+        std::uint16_t quality_;
+        std::uint32_t dim_x_, dim_y_;
+        mutable std::mutex m_;
+        std::condition_variable cv_;
+        frame_stream stream_;
+        std::mutex spare_m_;
+        std::vector<std::vector<float>> spare_; // declared before ring_: the entries' deleters use it while ring_ is destroyed
+        std::vector<std::shared_ptr<const entry>> ring_;
+        std::uint64_t produced_ = 0, end_ = 0;
+        bool producing_ = false, ended_ = false;
+        counters stats_;
     };
 }
 

@@ -5,7 +5,9 @@ the GPU box has. This module selects the MKL-free known-answer checks of tests/t
 values of the reference's OpenMP path: weighted-projection FNV over every pixel, K values, filtered values, volume
 sums and spot values, slab == slices, ROI == crop, thread-count independence, the cube geometries -- under the `gpu`
 marker too, so the box that runs the parity tests also records that its oracle build reproduces the pin. (The same
-functions run in the CPU suite under `-m "not gpu"`; nothing here touches the GPU.)"""
+functions run in the CPU suite under `-m "not gpu"`; nothing here touches the GPU.) The one check that goes through MKL's
+FFTW3 interface stays in the CPU suite only: MKL picks its FFT code path by host CPU, so its last bits -- and with them the
+survey's two volume FNVs -- reproduce only on the CPU type the survey ran on (this build container), not on the GPU box.)"""
 import pytest
 
 import test_oracle_kat as K
@@ -24,5 +26,4 @@ test_full_volume_values = K.test_full_volume_values
 test_slab_and_roi_identities = K.test_slab_and_roi_identities
 test_thread_count_independence = K.test_thread_count_independence
 test_cube_geometries = K.test_cube_geometries
-test_bit_exact_checksums_with_the_surveys_fft = K.test_bit_exact_checksums_with_the_surveys_fft
 test_committed_golden_fixtures_are_the_oracles_output = K.test_committed_golden_fixtures_are_the_oracles_output

@@ -98,6 +98,13 @@ def test_one_thread_per_device_fan_out(tmp_path, oracle):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("device ")]
     assert len(lines) == 3 and sum(int(l.split(":")[1].split()[0]) for l in lines) == 7  # 7 tasks over 3 threads
+    # the device threads share one read-once frame source per pass over the queue (7 tasks on 3 devices: 3 passes): every one
+    # of the 7 x 8 frame requests is answered, from memory when another thread of the pass has read the frame already (how many
+    # depends on how the three threads interleave; tests/test_io_formats.py pins the read-once property with controlled threads)
+    shared = [l for l in r.stdout.splitlines() if l.startswith("shared frame source:")]
+    assert len(shared) == 1
+    read, served = int(shared[0].split()[3]), int(shared[0].split()[9])
+    assert read + served == 7 * 8 and 3 * 8 <= read <= 7 * 8
     head, vol = F.ddbvf_read(str(tmp_path / "out" / "kat.ddbvf"))
     assert head == F.ddbvf_header_bytes(67, 67, 61)
     assert_close(vol, oracle_volume(oracle, range(8)))

@@ -221,3 +221,48 @@ def test_his_reader_random_files(io, tmp_path, seed):
     for a, b in zip(got, want):
         assert a.shape == b.shape == (h, w)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("capacity,delays,expect_reread", [(32, (0, 0, 0), False), (2, (0, 0, 3000), True)])
+def test_shared_frames_read_each_frame_once(io, tmp_path, capacity, delays, expect_reread):
+    """shared_frames (the read-once source of the multi-device driver): three consumers, each with its
+    own detector row band, get exactly frame_stream's frames, indices and angles; every frame is converted from the files
+    once; a consumer that lags further than the ring is deep falls back to its own stream and still gets the same data."""
+    io.paris_io_shared_scan.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p,
+                                        _u32p, C.c_uint32, C.c_uint32, _u32p, _u32p, _fp, _fp, C.POINTER(C.c_uint64)]
+    rng = np.random.default_rng(7)
+    d = tmp_path / "proj"
+    d.mkdir()
+    w, h = 9, 12
+    frames = []
+    for name, n in (("a.his", 5), ("b.his", 2), ("c.his", 6)):
+        fr = rng.integers(0, 60000, size=(n, h, w)).astype(np.float32)
+        frames += list(fr)
+        (d / name).write_bytes(F.his_file_bytes(fr, 4, 16))
+    (d / "b_broken.his").write_bytes(b"\x01" * 90)  # skipped by every stream
+    ang = tmp_path / "ang.txt"
+    ang.write_text(" ".join(str(2.5 * i) for i in range(len(frames))))
+    bands = [(0, h), (3, 4), (10, 2)]
+    for quality in (1, 2):
+        cap, nt = 16, 3
+        n = (C.c_uint32 * nt)()
+        idx = (C.c_uint32 * (nt * cap))()
+        phi = (C.c_float * (nt * cap))()
+        data = np.full((nt, cap, h, w), -7.0, np.float32)
+        counters = (C.c_uint64 * 3)()
+        rc = io.paris_io_shared_scan(str(d).encode(), 1, str(ang).encode(), quality, w, h, nt, (C.c_uint32 * nt)(*[b[0] for b in bands]),
+                                     (C.c_uint32 * nt)(*[b[1] for b in bands]), (C.c_uint32 * nt)(*delays), capacity, cap, n, idx, phi,
+                                     data.ctypes.data_as(_fp), counters)
+        assert rc == 0
+        keep = list(range(0, len(frames), quality))
+        for t, (first, count) in enumerate(bands):
+            assert n[t] == len(keep)
+            assert list(idx[t * cap:t * cap + n[t]]) == keep
+            assert list(phi[t * cap:t * cap + n[t]]) == [np.float32(2.5 * i) for i in keep]
+            for j, i in enumerate(keep):
+                assert np.array_equal(data[t, j, first:first + count], frames[i][first:first + count])
+                assert np.all(data[t, j, :first] == -7.0) and np.all(data[t, j, first + count:] == -7.0)
+        produced, served, reread = counters[0], counters[1], counters[2]
+        assert produced == len(keep)                       # every kept frame converted from the files exactly once
+        assert served + reread == nt * len(keep)           # every request answered
+        assert (reread > 0) == expect_reread

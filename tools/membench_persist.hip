@@ -1,0 +1,160 @@
+// Ceiling of a PERSISTENT slice-major sweep of the volume stream (VERDICT r01 item 3 / DESIGN "what comes next" 1):
+// the z-walk tile kernel keeps 2048 workgroups at up to 16 different slices (16 MiB apart) at any time and streams
+// 5.9 TB/s bare; a linear sweep with no z reuse streams 6.5. Here a grid of exactly the resident workgroups owns a set of
+// (x,y) columns for the whole depth of the slab and walks z with IF slices in flight, so the column state a real kernel
+// needs would be computed once per column; optionally the workgroups of one XCD pace each other with a relaxed counter
+// (no data is handed over, so no fences: pure pacing) so that they stay within LAG chunks of S slices of each other.
+// Every variant adds 1 to every voxel exactly once per launch (checked on a sample).
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/membench_persist.hip -o tools/membench_persist && tools/membench_persist [dz]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if(e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while(0)
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4f ld(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p)); }
+__device__ __forceinline__ void st(float* p, v4f a) { asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(a) : "memory"); }
+
+// today's pattern, for reference on the same box: 64 x 16 x TZ tiles, XCD-contiguous order, 2 slices in flight
+template <int TZ>
+__global__ void __launch_bounds__(256) tile_today(float* vol, uint32_t dx, uint32_t dy, uint32_t dz)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t ntx = dx / 64, nty = dy / 16, ntz = dz / TZ;
+    const uint32_t per = (ntx * nty * ntz) / 8u;
+    uint32_t b = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
+    const uint32_t bx = b % ntx; b /= ntx;
+    const uint32_t by = b % nty; const uint32_t bz = b / nty;
+    const uint32_t k = bx * 64 + (lane & 15u) * 4u;
+    const uint32_t l = by * 16 + wave * 4 + (lane >> 4);
+    const size_t slice = (size_t)dx * dy;
+    float* vp = vol + ((size_t)bz * TZ * dy + l) * dx + k;
+    for(uint32_t mm = 0; mm + 1 < TZ; mm += 2)
+    {
+        v4f a = ld(vp + mm * slice), c = ld(vp + (mm + 1) * slice);
+        a += 1.f; c += 1.f;
+        st(vp + mm * slice, a); st(vp + (mm + 1) * slice, c);
+    }
+}
+
+// linear sweep, one 16-byte load + store per thread, 64 lanes along x (the 6.5 TB/s ceiling)
+__global__ void __launch_bounds__(256) linear(float* vol)
+{
+    float* p = vol + ((size_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+    v4f a = ld(p); a += 1.f; st(p, a);
+}
+
+// Persistent sweep. Grid = 8 * WPX workgroups (WPX per XCD, all resident). XL = lanes along x per wave (16: tile 64 x 16,
+// 64: tile 256 x 4). XCD k owns a band of rows inside each pass; a pass covers 8 bands; passes = dy / (8 * band rows).
+// IF slices in flight per lane. S > 0: after every S slices a workgroup adds 1 to its XCD's counter and waits (bounded)
+// until every workgroup of the XCD has finished chunk c - LAG.
+template <int XL, int IF, int S, int LAG>
+__global__ void __launch_bounds__(256) persist(float* vol, uint32_t dx, uint32_t dy, uint32_t dz, uint32_t wpx,
+                                               unsigned* counters, unsigned epoch_base)
+{
+    constexpr uint32_t TX = XL * 4u, TY = 256u / XL;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t xcd = blockIdx.x % 8u, r = blockIdx.x / 8u;
+    const uint32_t ntx = dx / TX;
+    const uint32_t bx = r % ntx, byl = r / ntx;
+    const uint32_t band = (wpx / ntx) * TY;          // rows per XCD band
+    const uint32_t passes = dy / (8u * band);
+    const uint32_t k = bx * TX + (lane % XL) * 4u;
+    const uint32_t lrow = byl * TY + wave * (64u / XL) + lane / XL;
+    const size_t slice = (size_t)dx * dy;
+    unsigned* cnt = counters + xcd * 64u;            // one counter per XCD, 256 B apart
+    unsigned chunk = 0;
+    for(uint32_t pass = 0; pass < passes; ++pass)
+    {
+        const uint32_t l = (pass * 8u + xcd) * band + lrow;
+        float* vp = vol + (size_t)l * dx + k;
+        v4f q[IF];
+#pragma unroll
+        for(int i = 0; i < IF; ++i)
+            q[i] = ld(vp + (size_t)i * slice);
+        for(uint32_t m = 0; m < dz; m += IF)
+        {
+#pragma unroll
+            for(int i = 0; i < IF; ++i)
+            {
+                v4f a = q[i];
+                if(m + IF + i < dz)
+                    q[i] = ld(vp + (size_t)(m + IF + i) * slice);
+                a += 1.f;
+                st(vp + (size_t)(m + i) * slice, a);
+            }
+            if(S > 0 && ((m + IF) % S) == 0)
+            {
+                ++chunk;
+                if(threadIdx.x == 0)
+                {
+                    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if(chunk > LAG)
+                    {
+                        const unsigned want = epoch_base + (chunk - LAG) * wpx;
+                        for(int spin = 0; spin < (1 << 14); ++spin) // bounded: pacing only, never correctness
+                        {
+                            if((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0)
+                                break;
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+hipEvent_t ea, eb;
+struct Variant { std::string name; std::function<void()> f; std::vector<float> ms; };
+
+int main(int argc, char** argv)
+{
+    const uint32_t dx = 2048, dy = 2048, dz = argc > 1 ? atoi(argv[1]) : 256;
+    const size_t n = (size_t)dx * dy * dz;
+    float* a; CK(hipMalloc(&a, n * 4)); CK(hipMemset(a, 0, n * 4));
+    unsigned* cnt; CK(hipMalloc(&cnt, 8 * 64 * 4)); CK(hipMemset(cnt, 0, 8 * 64 * 4));
+    CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+    const double gb = 2.0 * n * 4 / 1e9;
+    std::vector<Variant> vs;
+    vs.push_back({"today: tile 64x16x16, 2 in flight", [=] { tile_today<16><<<(dx / 64) * (dy / 16) * (dz / 16), 256>>>(a, dx, dy, dz); }, {}});
+    vs.push_back({"linear depth 1 (ceiling)", [=] { linear<<<(unsigned)(n / 1024), 256>>>(a); }, {}});
+#define ADDP(XL, IF, WPX) vs.push_back({"persist XL" #XL " IF" #IF " wpx" #WPX " no pacing", [=] { persist<XL, IF, 0, 1><<<8 * WPX, 256>>>(a, dx, dy, dz, WPX, cnt, 0); }, {}})
+    ADDP(16, 2, 256); ADDP(16, 4, 256); ADDP(64, 2, 256); ADDP(64, 4, 256); ADDP(16, 2, 128); ADDP(16, 4, 128); ADDP(64, 4, 128); ADDP(16, 8, 64);
+    // paced variants: each gets its own counter block so epochs never mix
+    std::vector<unsigned*> cbs;
+#define ADDS(XL, IF, S, LAG, WPX) { unsigned* c; CK(hipMalloc(&c, 8 * 64 * 4)); CK(hipMemset(c, 0, 8 * 64 * 4)); cbs.push_back(c); \
+        unsigned* ep = new unsigned(0); const unsigned chunks = (2048u / (8u * ((WPX / (dx / (XL * 4u))) * (256u / XL)))) * (dz / S); \
+        vs.push_back({"persist XL" #XL " IF" #IF " wpx" #WPX " pace S" #S " lag" #LAG, [=] { persist<XL, IF, S, LAG><<<8 * WPX, 256>>>(a, dx, dy, dz, WPX, c, *ep); *ep += chunks * WPX; }, {}}); }
+    ADDS(16, 2, 2, 1, 256); ADDS(16, 2, 4, 1, 256); ADDS(16, 2, 8, 1, 256); ADDS(16, 2, 16, 1, 256); ADDS(16, 2, 4, 2, 256);
+    ADDS(64, 2, 4, 1, 256); ADDS(64, 2, 8, 1, 256); ADDS(16, 4, 4, 1, 256); ADDS(16, 4, 8, 1, 256); ADDS(16, 4, 8, 1, 128);
+    for(auto& v : vs) v.f();
+    CK(hipDeviceSynchronize());
+    const int rounds = 7;
+    for(int round = 0; round < rounds; ++round)
+        for(auto& v : vs)
+        {
+            CK(hipEventRecord(ea)); v.f(); CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb));
+            float ms; CK(hipEventElapsedTime(&ms, ea, eb)); v.ms.push_back(ms);
+        }
+    for(auto& v : vs)
+    {
+        std::sort(v.ms.begin(), v.ms.end());
+        printf("%-48s median %.3f ms (min %.3f)  %.0f GB/s\n", v.name.c_str(), v.ms[rounds / 2], v.ms[0], gb / v.ms[rounds / 2] * 1e3);
+    }
+    std::vector<float> h(4096);
+    const float want = (float)((rounds + 1) * vs.size());
+    for(size_t at : {(size_t)0, n / 2, n - 4096, n / 3})
+    {
+        CK(hipMemcpy(h.data(), a + at, h.size() * 4, hipMemcpyDeviceToHost));
+        for(float x : h) if(x != want) { printf("MISMATCH %f != %f at %zu\n", x, want, at); return 1; }
+    }
+    printf("sample check ok (%g)\n", want);
+    return 0;
+}
