@@ -218,6 +218,12 @@ def main():
     ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default: LOCAL_RANK)")
     ap.add_argument("--row-band", type=int, default=1, help="1 (default): each rank uploads, weights and filters only the "
                     "detector rows its z-slab can read (paris_hip_slab_row_band; the whole detector at N = 1); 0: all rows")
+    ap.add_argument("--stage-fusion", type=int, default=1, help="1 (default): weight + filter in one launch (paris_hip_set_stage_fusion); "
+                    "0: one launch per call")
+    ap.add_argument("--graph", type=int, default=0, help="1: every timed step is captured once into a hipGraph (torch.cuda.graph on "
+                    "the bench stream: copy + weight/filter + backproject of all its projections, angles baked in) before the timed "
+                    "region and replayed inside it -- for the launch-bound small configurations; kernel times then come from a "
+                    "separate eager pass (events cannot be read back from a captured stream)")
     ap.add_argument("--slices", type=int, default=0, help="rehearsal only: cap the volume depth (0 = the workload's)")
     ap.add_argument("--final-gather", choices=["checksums", "slabs", "off"], default="checksums",
                     help="N > 1, after the timed region and timed separately: the job's one collective. checksums (default): "
@@ -274,6 +280,8 @@ def main():
     stream = None if mode == "private" else torch.cuda.current_stream(dev).cuda_stream
     be = B.Backend(dev_index, stream=stream, synchronous=False)
     be.set_backproject_tuning(args.vx, args.unroll, args.tz, args.lds_bytes)
+    # paris::weight is held back and rides along in the load of the paris::filter call that follows: one launch for the pair
+    be.set_stage_fusion(bool(args.stage_fusion))
 
     n_row, n_col, n_proj = w["n_row"], w["n_col"], w["n_proj"]
     batch = args.batch if args.batch > 0 else -(-n_proj // max(1, args.steps))
@@ -304,14 +312,14 @@ def main():
             p = projs[b]
             p.idx = (first_idx + j) % n_proj
             work[b, band].copy_(raw[b, band], non_blocking=True)              # stands in for the upload
-            B.weight_rows(be, p, det, band_first, band_count)                 # src/main.cpp:102
-            B.filter_rows(be, p, det, band_first, band_count)                 # :103
             if f16:
+                # config 5: weight + filter in one launch that stores the band as IEEE half (no separate conversion pass)
+                B.weight_filter_rows(be, p, det, band_first, band_count, half.data_ptr(), n_row * 2)
                 sn, cs = B.stage_angle(det, p.idx)
-                B._lib.check(be._L.paris_hip_convert_projection_f16(be._ctx, p.ptr, p.pitch, half.data_ptr(), n_row * 2, n_row,
-                                                                   n_col), "paris_hip_convert_projection_f16")
                 be.backproject_f16(half.data_ptr(), n_row * 2, n_row, n_col, d_vol, z_first, det, vol_geo, True, roi, sn, cs, 0.0, 0.0)
             else:
+                B.weight_rows(be, p, det, band_first, band_count)             # src/main.cpp:102 (held back: stage fusion)
+                B.filter_rows(be, p, det, band_first, band_count)             # :103 (weights in its load)
                 B.backproject(be, p, d_vol, z_first, det, vol_geo, False, roi is not None, roi)  # :104
             launched.append(p.idx)
 
@@ -337,17 +345,45 @@ def main():
     be.backproject_timing_arm(min(65536, max(1, timed_launches)))
     del launched[:]
 
+    graphs = None
+    if args.graph:
+        if mode != "side":
+            raise SystemExit("bench.py --graph needs the explicit bench stream (PARIS_BENCH_STREAM=side)")
+        # kernel durations for the roofline: one eager pass over the job with events, outside the timed region
+        for s in range(args.steps):
+            step(s * batch)
+        kernel_ms = be.backproject_timing_collect()
+        kernel_idx = launched[-len(kernel_ms):] if kernel_ms else []
+        be.backproject_timing_arm(0)  # no event records in the captured stream
+        graphs = []
+        for s in range(args.steps):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                step(s * batch)
+            graphs.append(g)
+        torch.cuda.synchronize()
+        # the eager pass and the captures each added the job once (a capture enqueues nothing): start the timed job from zero
+        vol.zero_()
+        torch.cuda.synchronize()
+
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(s * batch)
+    if graphs is not None:
+        for g in graphs:
+            g.replay()
+    else:
+        for s in range(args.steps):
+            step(s * batch)
     torch.cuda.synchronize()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
-    kernel_ms = be.backproject_timing_collect()
-    kernel_idx = launched[-len(kernel_ms):] if kernel_ms else []
+    if graphs is None:
+        kernel_ms = be.backproject_timing_collect()
+        kernel_idx = launched[-len(kernel_ms):] if kernel_ms else []
+    else:
+        be.backproject_timing_arm(1)
 
     # ---- extension, outside the headline: the same step with ONE fused launch per batch (paris_hip_backproject_batch)
     fused = None
@@ -362,11 +398,11 @@ def main():
             idx = [(first_idx + b) % n_proj for b in range(fb)]
             for b in range(fb):
                 work[b, band].copy_(raw[b, band], non_blocking=True)
-                B.weight_rows(be, projs[b], det, band_first, band_count)
-                B.filter_rows(be, projs[b], det, band_first, band_count)
                 if f16:
-                    B._lib.check(be._L.paris_hip_convert_projection_f16(be._ctx, projs[b].ptr, pitch, halves[b].data_ptr(), n_row * 2,
-                                                                       n_row, n_col), "paris_hip_convert_projection_f16")
+                    B.weight_filter_rows(be, projs[b], det, band_first, band_count, halves[b].data_ptr(), n_row * 2)
+                else:
+                    B.weight_rows(be, projs[b], det, band_first, band_count)
+                    B.filter_rows(be, projs[b], det, band_first, band_count)
             if f16:
                 be.backproject_batch_f16(halves.data_ptr(), n_row * 2, n_row * n_col * 2, fb, n_row, n_col, d_vol, z_first, det,
                                          vol_geo, roi is not None, roi, [sc[i][0] for i in idx], [sc[i][1] for i in idx], 0.0, 0.0)
@@ -463,6 +499,8 @@ def main():
                 "slab_per_gpu": [out_geo.dim_x, out_geo.dim_y, z_count],
                 "detector_row_band_rank0": [band_first, band_count],
                 "parallelism": "z-slab per GPU, no collective on the data path",
+                "stage_fusion": bool(args.stage_fusion),
+                "hip_graph": bool(args.graph),
                 "backproject_kernel_ms": avg_ms,
                 "backproject_kernel_ms_min": min(kernel_ms) if kernel_ms else 0.0,
                 "backproject_kernel_ms_max": max(kernel_ms) if kernel_ms else 0.0,

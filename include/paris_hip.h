@@ -183,9 +183,29 @@ int paris_hip_set_filter_window(paris_hip_ctx* ctx, int window);
 int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
                            const float* d_k, uint32_t filter_size, uint32_t n_col);
 
-/* Row-filter kernel: 0 = default (radix-16 register passes for filter_size >= 1024, radix-2 below), 1 = the radix-2
- * kernel for every size (cross-check). Same transform; results differ by fp32 rounding only. */
+/* Row-filter kernel: 0 = default (filter_size >= 1024 and a K of paris_hip_make_filter*: radix-16 register passes with
+ * table twiddles, the kernel that can also weight in its load; radix-2 below 1024), 1 = the radix-2 kernel for every size,
+ * 2 = the first radix-16 kernel (twiddles formed per stage). Same transform; results differ by fp32 rounding only. */
 int paris_hip_set_filter_variant(paris_hip_ctx* ctx, int variant);
+
+/* Extension: stage fusion. With enable != 0 a paris_hip_weight / paris_hip_weight_rows call is held back, and the
+ * paris_hip_apply_filter call that follows on the same rows runs ONE kernel that applies the weight as it loads the row
+ * (same operations, each rounded once: the transform sees the bits the separate weighting would have stored) -- one launch
+ * and 8 instead of 16 bytes of memory traffic per pixel for PARIS's unchanged weight(); filter() call pair
+ * (src/main.cpp:102-103). Every other entry point that reads, writes, frees or waits for device data first runs a held-back
+ * weighting as its own kernel, so results never depend on the switch; only work the CALLER enqueues on the ctx stream between
+ * the two calls would see the rows unweighted. Off by default in the C library (reference behaviour call by call), switched
+ * on by paris::hip (C++ mirror) and bench.py. Ignored under PARIS_HIP_CTX_SYNCHRONOUS. */
+int paris_hip_set_stage_fusion(paris_hip_ctx* ctx, int enable);
+
+/* Extension: weighting and row filter of rows [row_first, row_first + row_count) in one launch, explicitly. d_half != NULL:
+ * the filtered rows are stored as IEEE half (round to nearest even) into d_half (same row numbering, half_pitch bytes per
+ * row) and the fp32 rows stay as they were (BASELINE config 5: saves the conversion pass). d_k must come from
+ * paris_hip_make_filter* on this ctx and filter_size must be >= 1024: PARIS_HIP_ERROR_UNSUPPORTED otherwise. */
+int paris_hip_weight_filter_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                                 uint32_t row_first, uint32_t row_count, float h_min, float v_min, float d_sd,
+                                 float l_px_row, float l_px_col, const float* d_k, uint32_t filter_size, uint16_t* d_half,
+                                 size_t half_pitch);
 
 /* ---- backprojection: backend::backproject (src/openmp/backprojection.cpp:156-199,
  *      src/cuda/backprojection.cu:133-243) ---------------------------------------------------------- */
@@ -271,6 +291,12 @@ int paris_hip_stage_weight_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, ui
                                 uint32_t row_first, uint32_t row_count, const paris_detector_geometry* det_geo);
 int paris_hip_stage_filter_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
                                 uint32_t row_first, uint32_t row_count, const paris_detector_geometry* det_geo);
+/* Extension: paris::weight + paris::filter of a row band in one launch (paris_hip_weight_filter_rows with the wrappers'
+ * constants and cached K); d_half != NULL stores the band as IEEE half there (half_pitch bytes per row, same row numbering)
+ * and leaves the fp32 rows unfiltered. Narrow detectors (filter length < 1024) run the separate stages: same result. */
+int paris_hip_stage_weight_filter_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                                       uint32_t row_first, uint32_t row_count, const paris_detector_geometry* det_geo,
+                                       uint16_t* d_half, size_t half_pitch);
 /* Extension (f4; no reference counterpart): the detector rows [*row_first, *row_first +
  * *row_count) that backprojecting into the slab (v_dim_*, v_offset, optional ROI; arguments as paris_hip_backproject)
  * can read for ANY projection angle. Rows outside the band never contribute to the slab, so a driver may upload,
@@ -300,7 +326,8 @@ const char* paris_hip_version(void);
 int paris_hip_last_backproject_ms(paris_hip_ctx* ctx, float* ms);
 /* Arms a ring of `capacity` HIP event pairs: every following backproject launch on this ctx is bracketed by
  * events on the ctx stream. _collect synchronises the stream and returns the durations (ms) of the launches
- * still in the ring, oldest first. Default capacity is 1 (paris_hip_last_backproject_ms). */
+ * still in the ring, oldest first. Default capacity is 1 (paris_hip_last_backproject_ms). Capacity 0 switches the events
+ * off (nothing but kernels and copies is enqueued: what a caller capturing the ctx stream into a hipGraph wants). */
 int paris_hip_backproject_timing_arm(paris_hip_ctx* ctx, uint32_t capacity);
 int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* ms, uint32_t max_n, uint32_t* n_out);
 /* Selects the backprojection kernel: 0 = default (currently the tile kernel), 1 = one-thread-per-voxel gather kernel

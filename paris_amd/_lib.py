@@ -79,6 +79,9 @@ SIGNATURES = {
     "paris_hip_memset_volume": (C.c_int, [_vp, _vp, _u32, _u32, _u32]),
     "paris_hip_make_subvolume_information": (C.c_int, [_P(VolumeGeometry), _P(DetectorGeometry), C.c_int,
                                                        _P(SubvolumeInfo)]),
+    "paris_hip_make_subvolume_information_reserving": (C.c_int, [_P(VolumeGeometry), _P(DetectorGeometry), C.c_int, _sz,
+                                                                 _P(SubvolumeInfo)]),
+    "paris_hip_device_memory": (C.c_int, [C.c_int, _P(_sz), _P(_sz)]),
     "paris_hip_weight": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _f, _f, _f, _f, _f]),
     "paris_hip_weight_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _f, _f, _f, _f, _f]),
     "paris_hip_make_filter": (C.c_int, [_vp, _u32, _f, _P(_vp)]),
@@ -86,6 +89,8 @@ SIGNATURES = {
     "paris_hip_set_filter_window": (C.c_int, [_vp, C.c_int]),
     "paris_hip_apply_filter": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _u32, _u32]),
     "paris_hip_set_filter_variant": (C.c_int, [_vp, C.c_int]),
+    "paris_hip_set_stage_fusion": (C.c_int, [_vp, C.c_int]),
+    "paris_hip_weight_filter_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _f, _f, _f, _f, _f, _vp, _u32, _vp, _sz]),
     "paris_hip_backproject": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _u32, _u32, _u32, _u32,
                                         _P(DetectorGeometry), _P(VolumeGeometry), C.c_int,
                                         _P(RegionOfInterest), _f, _f, _f, _f]),
@@ -106,6 +111,7 @@ SIGNATURES = {
     "paris_hip_stage_filter": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _P(DetectorGeometry)]),
     "paris_hip_stage_weight_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _P(DetectorGeometry)]),
     "paris_hip_stage_filter_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _P(DetectorGeometry)]),
+    "paris_hip_stage_weight_filter_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _P(DetectorGeometry), _vp, _sz]),
     "paris_hip_set_backproject_deferral": (C.c_int, [_vp, _u32]),
     "paris_hip_flush": (C.c_int, [_vp]),
     "paris_hip_slab_row_band": (C.c_int, [_P(DetectorGeometry), _P(VolumeGeometry), _u32, _u32, _u32, _u32, C.c_int,

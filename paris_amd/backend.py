@@ -219,6 +219,17 @@ class Backend:
     def set_filter_variant(self, variant):
         check(self._L.paris_hip_set_filter_variant(self._ctx, variant), "paris_hip_set_filter_variant")
 
+    def set_stage_fusion(self, enable=True):
+        """weight() is held back and rides along in the load of the apply_filter() that follows (one launch)"""
+        check(self._L.paris_hip_set_stage_fusion(self._ctx, int(bool(enable))), "paris_hip_set_stage_fusion")
+
+    def weight_filter_rows(self, p, row_first, row_count, h_min, v_min, d_sd, l_px_row, l_px_col, k, filter_size, half_ptr=None,
+                           half_pitch=0):
+        """weighting + row filter of a band of rows in one launch (extension); half_ptr: store IEEE half there instead"""
+        check(self._L.paris_hip_weight_filter_rows(self._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, row_first, row_count, h_min, v_min,
+                                                   d_sd, l_px_row, l_px_col, k.ptr, filter_size, half_ptr, half_pitch),
+              "paris_hip_weight_filter_rows")
+
     def backproject(self, p, v, v_offset, det_geo, vol_geo, enable_roi, roi, sin, cos, delta_s, delta_t):
         """backend::backproject (src/openmp/backprojection.cpp:156-199)"""
         r = roi if roi is not None else RegionOfInterest()
@@ -405,6 +416,13 @@ def filter_rows(backend, p, det_geo, row_first, row_count):
     """paris::filter on the rows of a band only (paris_hip_stage_filter_rows)"""
     check(backend._L.paris_hip_stage_filter_rows(backend._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, row_first, row_count,
                                                  C.byref(det_geo)), "paris_hip_stage_filter_rows")
+
+
+def weight_filter_rows(backend, p, det_geo, row_first, row_count, half_ptr=None, half_pitch=0):
+    """paris::weight + paris::filter of a row band in one launch (paris_hip_stage_weight_filter_rows); half_ptr: store the
+    filtered band as IEEE half there instead of fp32 in place"""
+    check(backend._L.paris_hip_stage_weight_filter_rows(backend._ctx, p.ptr, p.pitch, p.dim_x, p.dim_y, row_first, row_count,
+                                                        C.byref(det_geo), half_ptr, half_pitch), "paris_hip_stage_weight_filter_rows")
 
 
 def backproject(backend, p, v, v_offset, det_geo, vol_geo, enable_angles, enable_roi, roi):

@@ -494,6 +494,8 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     skip = false;
     if(int rc = paris_hip_bind(ctx))
         return rc;
+    if(int rc = paris_hip_flush_pending_weight(ctx)) // a weighting that no filter call picked up
+        return rc;
     if(d_p == nullptr || d_v == nullptr || det_geo == nullptr || vol_geo == nullptr || (enable_roi && roi == nullptr))
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(p_dim_x == 0 || p_dim_y == 0 || p_pitch < static_cast<size_t>(p_dim_x) * px || p_pitch % px != 0)
@@ -503,7 +505,10 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
         skip = true;
         return PARIS_HIP_SUCCESS;
     }
-    const uint32_t tz = ctx->bp_tz ? ctx->bp_tz : TZ_DEFAULT;
+    // tile depth: 16 slices, 8 for planes of 1024^2 voxels and less (+2.5 % on the 1024^3 volume: shorter z-walks keep
+    // the concurrently touched slices of the smaller planes closer together; profiles/r02_tune_bp_c2.jsonl)
+    const bool small_plane = static_cast<uint64_t>(v_dim_x) * v_dim_y <= (1ull << 20) && static_cast<uint64_t>(v_dim_x) * v_dim_y > (1ull << 18);
+    const uint32_t tz = ctx->bp_tz ? ctx->bp_tz : (small_plane ? 8u : TZ_DEFAULT);
     {
         // the 1-D grid must hold every tile (narrowest tile: 64 x 4 x tz)
         const uint64_t tiles = static_cast<uint64_t>((v_dim_x + 63u) / 64u) * ((v_dim_y + 3u) / 4u) * ((v_dim_z + std::min(tz, 8u) - 1u) / std::min(tz, 8u));
@@ -589,8 +594,10 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
     if(skip)
         return paris_hip_finish(ctx);
 
-    const size_t ev = static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size());
-    PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
+    const bool timed = !ctx->bp_start.empty(); // paris_hip_backproject_timing_arm(ctx, 0): no events (stream capture)
+    const size_t ev = timed ? static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size()) : 0u;
+    if(timed)
+        PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
     if(ctx->bp_variant == 4 && !f16) // the fused kernel with a single projection (measurement: all slices of a tile in flight)
     {
         FusedParams fp;
@@ -616,7 +623,9 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         int vx = lane_width(d_v, v_dim_x); // unless the tuning knob asks for less
         if(ctx->bp_vx && ctx->bp_vx < vx)
             vx = ctx->bp_vx;
-        const int unroll = ctx->bp_unroll ? ctx->bp_unroll : 2; // interleaved A/B on 2048^3 (tools/ab_bp.py, profiles/)
+        // slices in flight per lane: 2 (interleaved A/B on 2048^3: tools/ab_bp.py, profiles/); with the 8-slice tiles of
+        // 1024^2 planes one slice plus the prefetch of the next is as fast and leaves more registers
+        const int unroll = ctx->bp_unroll ? ctx->bp_unroll : (g.tz == 8u && ctx->bp_tz == 0u ? 1 : 2);
         const bool nt = ctx->bp_nt != 0;
         const bool want_slice = ctx->bp_variant == 3; // measured slower than the tile kernel so far: opt-in only
         if(want_slice && vx == 4)
@@ -634,7 +643,8 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         else
             launch_tile_flags<1>(g, unroll, nt, fd, ctx->stream);
     }
-    PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
+    if(timed)
+        PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
     ++ctx->bp_launches;
     if(int rc = paris_hip_note_projection_use(ctx, d_p))
         return rc;
@@ -653,6 +663,9 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
 
 int paris_hip_flush_deferred(paris_hip_ctx* ctx)
 {
+    if(ctx != nullptr && ctx->pending_weight.active) // every observer of device state also sees a held-back weighting done
+        if(int rc = paris_hip_flush_pending_weight(ctx))
+            return rc;
     if(ctx == nullptr || ctx->defer_count == 0)
         return PARIS_HIP_SUCCESS;
     const uint32_t n = ctx->defer_count;
@@ -793,6 +806,8 @@ extern "C" int paris_hip_convert_projection_f16(paris_hip_ctx* ctx, const float*
 {
     if(int rc = paris_hip_bind(ctx))
         return rc;
+    if(int rc = paris_hip_flush_pending_weight(ctx))
+        return rc;
     if(d_src == nullptr || d_dst == nullptr || src_pitch % sizeof(float) != 0 || dst_pitch % sizeof(uint16_t) != 0
        || src_pitch < static_cast<size_t>(dim_x) * sizeof(float) || dst_pitch < static_cast<size_t>(dim_x) * sizeof(uint16_t))
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
@@ -901,10 +916,13 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
             fp.sin_phi[i] = sin_phi[first + i];
             fp.cos_phi[i] = cos_phi[first + i];
         }
-        const size_t ev = static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size());
-        PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
+        const bool timed = !ctx->bp_start.empty();
+        const size_t ev = timed ? static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size()) : 0u;
+        if(timed)
+            PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
         paris_hip_bp_launch_fused(&fp, fused_vx, tz16 ? 16 : 8, nt, fd, ctx->stream);
-        PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
+        if(timed)
+            PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
         ++ctx->bp_launches;
         for(uint32_t i = 0; i < n && !ctx->upload_targets.empty(); ++i)
             if(int rc = paris_hip_note_projection_use(ctx, p0 + static_cast<size_t>(i) * p_stride_bytes))
@@ -917,7 +935,7 @@ extern "C" int paris_hip_last_backproject_ms(paris_hip_ctx* ctx, float* ms)
 {
     if(int rc = paris_hip_flush_deferred(ctx))
         return rc;
-    if(ctx == nullptr || ms == nullptr || ctx->bp_launches == 0)
+    if(ctx == nullptr || ms == nullptr || ctx->bp_launches == 0 || ctx->bp_start.empty())
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(int rc = paris_hip_bind(ctx))
         return rc;

@@ -110,9 +110,15 @@ extern "C" int paris_hip_backproject_timing_arm(paris_hip_ctx* ctx, uint32_t cap
         return rc;
     if(int rc = paris_hip_bind(ctx))
         return rc;
-    if(capacity == 0 || capacity > 65536u)
+    if(capacity > 65536u)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if(capacity == 0) // no events around the launches at all: what a caller capturing the ctx stream into a hipGraph wants
+    {
+        destroy_events(ctx);
+        ctx->bp_launches = 0;
+        return PARIS_HIP_SUCCESS;
+    }
     if(ctx->bp_start.size() != capacity)
     {
         destroy_events(ctx);
@@ -139,6 +145,11 @@ extern "C" int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* m
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const uint64_t cap = ctx->bp_start.size();
+    if(cap == 0)
+    {
+        *n_out = 0;
+        return PARIS_HIP_SUCCESS;
+    }
     const uint64_t have = ctx->bp_launches < cap ? ctx->bp_launches : cap;
     const uint64_t first = ctx->bp_launches - have; // oldest launch still in the ring
     uint32_t n = 0;
@@ -156,8 +167,19 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream); // NULL: the legacy default stream
     if(ctx->upload_stream != nullptr)
         (void)hipStreamSynchronize(ctx->upload_stream);
+    ctx->pending_weight.active = false; // a weighting nobody filtered or read: dropped with the ctx
     for(auto& kv : ctx->plans)
+    {
         (void)hipFree(kv.second.d_twiddle);
+        if(kv.second.d_tab_first != nullptr)
+            (void)hipFree(kv.second.d_tab_first);
+        for(float2* t : kv.second.d_tab_mid)
+            if(t != nullptr)
+                (void)hipFree(t);
+    }
+    for(auto& kv : ctx->filters)
+        if(kv.second.d_kp != nullptr)
+            (void)hipFree(kv.second.d_kp);
     if(ctx->d_sincos != nullptr)
         (void)hipFree(ctx->d_sincos);
     for(auto& kv : ctx->proj_pool)
@@ -397,6 +419,16 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
         return rc;
     if(d_ptr == nullptr)
         return PARIS_HIP_SUCCESS;
+    if(int rc = paris_hip_flush_pending_weight(ctx))
+        return rc;
+    auto filt = ctx->filters.find(static_cast<const float*>(d_ptr));
+    if(filt != ctx->filters.end())
+    {
+        PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream)); // a filter launch may still read the permuted copy
+        if(filt->second.d_kp != nullptr)
+            PARIS_HIP_TRY(hipFree(filt->second.d_kp));
+        ctx->filters.erase(filt);
+    }
     auto proj = ctx->proj_allocs.find(d_ptr);
     if(proj != ctx->proj_allocs.end())
     {
@@ -487,6 +519,8 @@ extern "C" int paris_hip_memcpy_projection_h2d(paris_hip_ctx* ctx, float* d_dst,
 {
     if(int rc = paris_hip_bind(ctx))
         return rc;
+    if(int rc = paris_hip_flush_pending_weight(ctx))
+        return rc;
     if(d_dst == nullptr || h_src == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
@@ -498,6 +532,8 @@ extern "C" int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, siz
                                            uint32_t dim_x, uint32_t dim_y)
 {
     if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(int rc = paris_hip_flush_pending_weight(ctx))
         return rc;
     if(d_dst == nullptr || h_src == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
@@ -539,6 +575,8 @@ extern "C" int paris_hip_memcpy_projection_d2h(paris_hip_ctx* ctx, float* h_dst,
                                                size_t d_pitch, uint32_t dim_x, uint32_t dim_y)
 {
     if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(int rc = paris_hip_flush_pending_weight(ctx))
         return rc;
     if(h_dst == nullptr || d_src == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;

@@ -465,6 +465,8 @@ int paris_hip_get_plan(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_plan** out)
         // one-off, tiny: a synchronous copy keeps the pageable staging vector alive long enough
         PARIS_HIP_TRY(hipMemcpy(plan.d_twiddle, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
         it = ctx->plans.emplace(n, plan).first;
+        if(int rc = paris_hip_fused_filter_tables(ctx, n, &it->second)) // n >= 1024: the fused kernel's inter-pass twiddles
+            return rc;
     }
     *out = &it->second;
     return PARIS_HIP_SUCCESS;
@@ -491,8 +493,29 @@ extern "C" int paris_hip_make_filter_windowed(paris_hip_ctx* ctx, uint32_t size,
     PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&k), (size / 2 + 1) * sizeof(float)));
     hipLaunchKernelGGL(make_filter_kernel, dim3(1), dim3(threads_for(size)), size * sizeof(float2), ctx->stream, k,
                        plan->d_twiddle, ilog2(size), tau, window);
+    paris_hip_filter_info info;
+    info.size = size;
+    if(size >= 1024u) // the fused kernel reads K in the order its middle pass holds the frequencies
+        if(int rc = paris_hip_fused_filter_permute_k(ctx, k, size, &info.d_kp))
+        {
+            (void)hipFree(k);
+            return rc;
+        }
+    ctx->filters[k] = info;
     *d_k = k;
     return paris_hip_finish(ctx);
+}
+
+// which kernel serves a filter call: the table-twiddle kernel of filter_fused.hip needs a K made by paris_hip_make_filter*
+// on this ctx (its permuted copy) and a length >= 1024; filter_variant 1 / 2 force the radix-2 / the first radix-16 kernel
+static const paris_hip_filter_info* fused_filter_of(paris_hip_ctx* ctx, const float* d_k, uint32_t filter_size)
+{
+    if(ctx->filter_variant != 0 || filter_size < 1024u)
+        return nullptr;
+    auto it = ctx->filters.find(d_k);
+    if(it == ctx->filters.end() || it->second.size != filter_size || it->second.d_kp == nullptr)
+        return nullptr;
+    return &it->second;
 }
 
 extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
@@ -500,13 +523,18 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
 {
     if(int rc = paris_hip_bind(ctx))
         return rc;
-    if(d_p == nullptr || d_k == nullptr || !is_pow2(filter_size) || filter_size < MIN_N || filter_size > MAX_N)
+    if(d_p == nullptr || d_k == nullptr || !is_pow2(filter_size) || filter_size < MIN_N || filter_size > MAX_N
+       || dim_x > filter_size || n_col != dim_y || pitch < static_cast<size_t>(dim_x) * sizeof(float) || pitch % sizeof(float) != 0)
+    {
+        (void)paris_hip_flush_pending_weight(ctx);
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    if(dim_x > filter_size || n_col != dim_y || pitch < static_cast<size_t>(dim_x) * sizeof(float)
-       || pitch % sizeof(float) != 0)
-        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    }
     if(dim_x == 0 || dim_y == 0)
+    {
+        if(int rc = paris_hip_flush_pending_weight(ctx))
+            return rc;
         return paris_hip_finish(ctx);
+    }
     if(int rc = ensure_lds_limit(ctx))
         return rc;
     paris_hip_fft_plan* plan = nullptr;
@@ -514,7 +542,26 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
         return rc;
     const uint32_t pitch_f = static_cast<uint32_t>(pitch / sizeof(float));
     const uint32_t log2n = ilog2(filter_size);
-    if(ctx->filter_variant == 0 && log2n >= 10u)
+    if(const paris_hip_filter_info* info = fused_filter_of(ctx, d_k, filter_size))
+    {
+        // a weighting held back for exactly these rows (stage fusion) rides along in the load
+        auto& w = ctx->pending_weight;
+        const bool fuse = w.active && w.pitch == pitch && w.dim_x == dim_x && w.row_count == dim_y
+                          && reinterpret_cast<char*>(w.d_p) + static_cast<size_t>(w.row_first) * w.pitch == reinterpret_cast<char*>(d_p);
+        if(fuse)
+            w.active = false;
+        else if(int rc = paris_hip_flush_pending_weight(ctx))
+            return rc;
+        if(int rc = paris_hip_fused_filter_launch(ctx, d_p, pitch_f, dim_x, dim_y, fuse ? w.row_first : 0u, fuse, w.h_min, w.v_min, w.d_sd,
+                                                  w.l_px_row, w.l_px_col, info->d_kp, plan, filter_size, nullptr, 0u))
+            return rc;
+        if(int rc = paris_hip_note_projection_use(ctx, d_p))
+            return rc;
+        return paris_hip_finish(ctx);
+    }
+    if(int rc = paris_hip_flush_pending_weight(ctx))
+        return rc;
+    if(ctx->filter_variant != 1 && log2n >= 10u)
     {
         int rc = PARIS_HIP_SUCCESS;
         switch(log2n)
@@ -538,10 +585,47 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
     return paris_hip_finish(ctx);
 }
 
+// Extension: cosine weighting and row filter of rows [row_first, row_first + row_count) in ONE launch (filter_fused.hip);
+// d_half != NULL: the filtered rows are stored as IEEE half into d_half (same row numbering, half_pitch bytes per row)
+// and the fp32 rows are left as they were. Needs a K of paris_hip_make_filter* and filter_size >= 1024
+// (PARIS_HIP_ERROR_UNSUPPORTED otherwise: the caller then runs the two stages).
+extern "C" int paris_hip_weight_filter_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y, uint32_t row_first,
+                                            uint32_t row_count, float h_min, float v_min, float d_sd, float l_px_row, float l_px_col,
+                                            const float* d_k, uint32_t filter_size, uint16_t* d_half, size_t half_pitch)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(int rc = paris_hip_flush_pending_weight(ctx))
+        return rc;
+    if(d_p == nullptr || d_k == nullptr || !is_pow2(filter_size) || filter_size < MIN_N || filter_size > MAX_N || dim_x > filter_size
+       || pitch < static_cast<size_t>(dim_x) * sizeof(float) || pitch % sizeof(float) != 0 || row_first > dim_y || row_count > dim_y - row_first
+       || (d_half != nullptr && (half_pitch < static_cast<size_t>(dim_x) * sizeof(uint16_t) || half_pitch % sizeof(uint16_t) != 0)))
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(dim_x == 0 || row_count == 0)
+        return paris_hip_finish(ctx);
+    const paris_hip_filter_info* info = fused_filter_of(ctx, d_k, filter_size);
+    if(info == nullptr)
+        return PARIS_HIP_ERROR_UNSUPPORTED;
+    paris_hip_fft_plan* plan = nullptr;
+    if(int rc = paris_hip_get_plan(ctx, filter_size, &plan))
+        return rc;
+    float* rows = reinterpret_cast<float*>(reinterpret_cast<char*>(d_p) + static_cast<size_t>(row_first) * pitch);
+    uint16_t* half_rows = d_half ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d_half) + static_cast<size_t>(row_first) * half_pitch) : nullptr;
+    if(int rc = paris_hip_fused_filter_launch(ctx, rows, static_cast<uint32_t>(pitch / sizeof(float)), dim_x, row_count, row_first, true, h_min, v_min,
+                                              d_sd, l_px_row, l_px_col, info->d_kp, plan, filter_size, half_rows,
+                                              static_cast<uint32_t>(half_pitch / sizeof(uint16_t))))
+        return rc;
+    if(int rc = paris_hip_note_projection_use(ctx, d_p))
+        return rc;
+    return paris_hip_finish(ctx);
+}
+
 extern "C" int paris_hip_set_filter_variant(paris_hip_ctx* ctx, int variant)
 {
-    if(ctx == nullptr || variant < 0 || variant > 1)
+    if(ctx == nullptr || variant < 0 || variant > 2)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(int rc = paris_hip_flush_pending_weight(ctx))
+        return rc;
     ctx->filter_variant = variant;
     return PARIS_HIP_SUCCESS;
 }

@@ -26,6 +26,16 @@
 struct paris_hip_fft_plan
 {
     float2* d_twiddle = nullptr; // exp(-2 pi i k / n), k < n/2
+    // fused weight + filter kernel (filter_fused.hip), n >= 1024: inter-pass twiddle tables W_B^(o q), rounded from double
+    float2* d_tab_first = nullptr;                  // first / last pass, B = n
+    float2* d_tab_mid[3] = {nullptr, nullptr, nullptr}; // middle passes with B = 256, 4096, 65536
+};
+
+// a filter K made by paris_hip_make_filter*: its length and the copy of K in the order the fused kernel's middle pass reads it
+struct paris_hip_filter_info
+{
+    uint32_t size = 0;
+    float* d_kp = nullptr;
 };
 
 struct paris_hip_ctx
@@ -51,6 +61,19 @@ struct paris_hip_ctx
     bool filter_r16_attr_set[5] = {false, false, false, false, false}; // LOG2N 10..14
     int filter_variant = 0; // 0: radix-16 register passes for N >= 1024, 1: radix-2 kernel for every N
     std::map<uint32_t, paris_hip_fft_plan> plans; // keyed by FFT length
+    std::map<const float*, paris_hip_filter_info> filters; // K buffers handed out by paris_hip_make_filter*, until paris_hip_free
+    // Stage fusion (paris_hip_set_stage_fusion): a paris_hip_weight[_rows] call is held back; the paris_hip_apply_filter call
+    // that follows on the same rows runs ONE kernel that weights in its load (filter_fused.hip). Anything else that touches a
+    // projection or completes work first runs the held-back weighting as its own kernel (paris_hip_flush_pending_weight).
+    int stage_fusion = 0;
+    struct pending_weight_t
+    {
+        bool active = false;
+        float* d_p = nullptr;
+        size_t pitch = 0;
+        uint32_t dim_x = 0, dim_y = 0, row_first = 0, row_count = 0;
+        float h_min = 0.f, v_min = 0.f, d_sd = 0.f, l_px_row = 0.f, l_px_col = 0.f;
+    } pending_weight;
     // dedicated upload stream + ring of events ordering the compute stream behind each upload (paris_hip_upload_projection)
     hipStream_t upload_stream = nullptr;
     std::vector<hipEvent_t> upload_events;
@@ -144,6 +167,16 @@ inline int paris_hip_bind(paris_hip_ctx* ctx)
 }
 
 int paris_hip_get_plan(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_plan** out);
+
+// weight.hip: runs a held-back weighting (stage fusion) as its own kernel; no-op when none is pending
+int paris_hip_flush_pending_weight(paris_hip_ctx* ctx);
+
+// filter_fused.hip
+int paris_hip_fused_filter_tables(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_plan* plan);
+int paris_hip_fused_filter_permute_k(paris_hip_ctx* ctx, const float* d_k, uint32_t n, float** d_kp);
+int paris_hip_fused_filter_launch(paris_hip_ctx* ctx, float* d_rows, uint32_t pitch_f, uint32_t dim_x, uint32_t n_rows, uint32_t row_first,
+                                  bool weight, float h_min, float v_min, float d_sd, float l_px_row, float l_px_col, const float* d_kp,
+                                  const paris_hip_fft_plan* plan, uint32_t filter_size, uint16_t* d_half, uint32_t half_pitch);
 
 // backproject.hip: runs the projections pending in the deferral ring (no-op when there are none). Called by every entry
 // point that observes or changes a volume, completes work, or changes how backprojection runs.

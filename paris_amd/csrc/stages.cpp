@@ -129,6 +129,40 @@ extern "C" int paris_hip_stage_filter_rows(paris_hip_ctx* ctx, float* d_p, size_
     return paris_hip_apply_filter(ctx, rows, pitch, dim_x, row_count, ctx->stage_k, filter_size, row_count);
 }
 
+// Extension: paris::weight + paris::filter of a row band in ONE launch (paris_hip_weight_filter_rows), optionally storing the
+// result as IEEE half into d_half (BASELINE config 5) instead of fp32 in place. Filter lengths below 1024 (detectors narrower
+// than 257 pixels) run the two stages (and the conversion) one after the other: same result.
+extern "C" int paris_hip_stage_weight_filter_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
+                                                  uint32_t row_first, uint32_t row_count, const paris_detector_geometry* det_geo,
+                                                  uint16_t* d_half, size_t half_pitch)
+{
+    if(ctx == nullptr || det_geo == nullptr || d_p == nullptr || row_first > dim_y || row_count > dim_y - row_first)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    const uint32_t filter_size = paris_hip_filter_size(det_geo->n_row);
+    if(filter_size >= 1024u && ctx->filter_variant == 0)
+    {
+        // K of the stage wrapper, built once per ctx and (filter_size, tau): the filter call below with no rows does just that
+        if(int rc = paris_hip_stage_filter_rows(ctx, d_p, pitch, dim_x, dim_y, row_first, 0u, det_geo))
+            return rc;
+        const float n_row_f = static_cast<float>(det_geo->n_row);
+        const float n_col_f = static_cast<float>(det_geo->n_col);
+        const float h_min = (det_geo->delta_s * det_geo->l_px_row) - ((n_row_f * det_geo->l_px_row) / 2); // src/weighting.cpp:37-42
+        const float v_min = (det_geo->delta_t * det_geo->l_px_col) - ((n_col_f * det_geo->l_px_col) / 2);
+        const float d_sd = std::abs(det_geo->d_so) + std::abs(det_geo->d_od);
+        return paris_hip_weight_filter_rows(ctx, d_p, pitch, dim_x, dim_y, row_first, row_count, h_min, v_min, d_sd, det_geo->l_px_row,
+                                            det_geo->l_px_col, ctx->stage_k, filter_size, d_half, half_pitch);
+    }
+    if(int rc = paris_hip_stage_weight_rows(ctx, d_p, pitch, dim_x, dim_y, row_first, row_count, det_geo))
+        return rc;
+    if(int rc = paris_hip_stage_filter_rows(ctx, d_p, pitch, dim_x, dim_y, row_first, row_count, det_geo))
+        return rc;
+    if(d_half == nullptr || row_count == 0)
+        return PARIS_HIP_SUCCESS;
+    return paris_hip_convert_projection_f16(ctx, reinterpret_cast<float*>(reinterpret_cast<char*>(d_p) + static_cast<size_t>(row_first) * pitch), pitch,
+                                            reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d_half) + static_cast<size_t>(row_first) * half_pitch),
+                                            half_pitch, dim_x, row_count);
+}
+
 extern "C" int paris_hip_stage_filter(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
                                       const paris_detector_geometry* det_geo)
 {

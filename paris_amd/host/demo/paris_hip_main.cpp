@@ -126,8 +126,8 @@ int main(int argc, char** argv)
         std::printf("volume %u x %u x %u (%d slab%s) -> %s in %.3f s\n", r.roi_geo.dim_x, r.roi_geo.dim_y, r.roi_geo.dim_z, r.info.num,
                     r.info.num == 1 ? "" : "s", r.output_file.c_str(), r.wall_s);
         if(r.devices.size() > 1)
-            std::printf("shared frame source: %llu frames read from the files, %llu served from memory\n",
-                        static_cast<unsigned long long>(r.frames_read), static_cast<unsigned long long>(r.frames_shared));
+            std::printf("shared frame source: %llu frames read from the files for %llu frame requests of the device threads\n",
+                        static_cast<unsigned long long>(r.frames_read), static_cast<unsigned long long>(r.frames_requested));
         for(const auto& s : r.skipped)
             std::printf("  skipped invalid file %s\n", s.c_str());
         for(const auto& d : r.devices)

@@ -17,6 +17,11 @@
 #ifndef PARIS_HIP_BACKPROJECT_DEFERRAL
 #define PARIS_HIP_BACKPROJECT_DEFERRAL 16
 #endif
+// 1 (default): weight() is held back and rides along in the load of the apply_filter() call that follows (one launch per
+// weight / filter pair of src/main.cpp:102-103; paris_hip_set_stage_fusion). 0: one launch per call.
+#ifndef PARIS_HIP_STAGE_FUSION
+#define PARIS_HIP_STAGE_FUSION 1
+#endif
 // 1: every backend call returns after its work has finished, like the reference's backends (stream sync before return:
 // src/cuda/weighting.cu:72, filtering.cu:260, backprojection.cu:236). 0 (default): calls enqueue and return; only the
 // copies to the host wait. The call sequence of src/main.cpp:98-105 observes results through copy_d2h alone, and the
@@ -120,6 +125,7 @@ namespace paris
                 // slab is read and written once per group instead of once per projection -- and flushes before anything
                 // observes the volume (copy_d2h, free): see paris_hip_set_backproject_deferral. 1 = one launch per call.
                 detail::construction_check(paris_hip_set_backproject_deferral(c, PARIS_HIP_BACKPROJECT_DEFERRAL), "set_device()");
+                detail::construction_check(paris_hip_set_stage_fusion(c, PARIS_HIP_STAGE_FUSION), "set_device()");
                 it = s.per_device.emplace(d, std::unique_ptr<paris_hip_ctx, detail::ctx_deleter>{c}).first;
             }
             s.current = it->second.get();

@@ -399,15 +399,13 @@ namespace paris
                     {
                         // :101 -- on the upload stream, overlapping the kernels of the previous projections
                         rt(paris_hip_upload_projection(ctx, d_band, d_pitch, h_buf[slot] + band_off, row_bytes, n_row, band_count), "load()");
-                        rt(paris_hip_stage_weight_rows(ctx, d_buf[slot], d_pitch, n_row, n_col, band_first, band_count, &t.det_geo), "weight()"); // :102
-                        rt(paris_hip_stage_filter_rows(ctx, d_buf[slot], d_pitch, n_row, n_col, band_first, band_count, &t.det_geo), "filter()"); // :103
+                        // :102-103 in one launch: the weight rides along in the row filter's load; with --f16 (BASELINE config 5) the
+                        // filtered band is stored as IEEE half straight into the slot's half frame
+                        auto* half_frame = po.f16 ? reinterpret_cast<std::uint16_t*>(reinterpret_cast<char*>(d_half) + h16_stride * static_cast<std::size_t>(slot)) : nullptr;
+                        rt(paris_hip_stage_weight_filter_rows(ctx, d_buf[slot], d_pitch, n_row, n_col, band_first, band_count, &t.det_geo, half_frame,
+                                                              h16_pitch), "weight() + filter()");
                     }
                     rt(paris_hip_stage_angle(&t.det_geo, p.idx, t.enable_angles, p.phi, &sines[filled], &cosines[filled]), "angle"); // src/backprojection.cpp:52-63
-                    if(po.f16 && band_count != 0) // BASELINE config 5: the filtered frame is rounded to IEEE half, its slot's band only
-                        rt(paris_hip_convert_projection_f16(ctx, d_band, d_pitch,
-                                                            reinterpret_cast<std::uint16_t*>(reinterpret_cast<char*>(d_half) + h16_stride * static_cast<std::size_t>(slot)
-                                                                                             + static_cast<std::size_t>(band_first) * h16_pitch),
-                                                            h16_pitch, n_row, band_count), "to half");
                     rep.enqueue_s += since(t0);
                     if(++filled == batch)
                         flush();
@@ -459,7 +457,7 @@ namespace paris
         volume_geometry vol_geo{}, roi_geo{};
         subvolume_info info{};
         std::vector<device_report> devices;
-        std::uint64_t frames_read = 0, frames_shared = 0; // several devices: frames converted from the files / copied from the shared source
+        std::uint64_t frames_read = 0, frames_requested = 0; // several devices: frames converted from the files / frames handed to device threads
         std::vector<std::string> skipped;                  // several devices: invalid files skipped by the shared source
         int batch = 0; // frames per fused launch actually used (program_options::batch, halved until the slots fit the devices)
         double wall_s = 0;
@@ -510,7 +508,7 @@ namespace paris
                 r.devices.push_back(f.get());
             const auto st = pool.stats();
             r.frames_read = st.produced + st.reread;
-            r.frames_shared = st.served;
+            r.frames_requested = st.served + st.reread;
             r.skipped = pool.skipped_files();
         }
         else

@@ -103,8 +103,8 @@ def test_one_thread_per_device_fan_out(tmp_path, oracle):
     # depends on how the three threads interleave; tests/test_io_formats.py pins the read-once property with controlled threads)
     shared = [l for l in r.stdout.splitlines() if l.startswith("shared frame source:")]
     assert len(shared) == 1
-    read, served = int(shared[0].split()[3]), int(shared[0].split()[9])
-    assert read + served == 7 * 8 and 3 * 8 <= read <= 7 * 8
+    read, requested = int(shared[0].split()[3]), int(shared[0].split()[10])
+    assert requested == 7 * 8 and 3 * 8 <= read <= 7 * 8
     head, vol = F.ddbvf_read(str(tmp_path / "out" / "kat.ddbvf"))
     assert head == F.ddbvf_header_bytes(67, 67, 61)
     assert_close(vol, oracle_volume(oracle, range(8)))

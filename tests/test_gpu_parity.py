@@ -144,7 +144,7 @@ def test_make_filter_golden(be, kat_golden):
         be.free(k)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("n_row,n_col", [(64, 48), (512, 37), (1000, 8), (5, 3), (2048, 6), (4097, 2), (3000, 5), (8192, 3)])
 def test_apply_filter(be, oracle, n_row, n_col, variant):
     fs = oracle.filter_size(n_row)
@@ -154,7 +154,7 @@ def test_apply_filter(be, oracle, n_row, n_col, variant):
     want = oracle.apply_filter(p.copy(), oracle.make_filter(fs, tau), fs)
     d_p = to_device(be, p)
     k = be.make_filter(fs, tau)
-    be.set_filter_variant(variant)  # 0: radix-16 register passes (N >= 1024), 1: radix-2 in LDS
+    be.set_filter_variant(variant)  # 0: radix-16 passes with table twiddles (N >= 1024), 1: radix-2 in LDS, 2: first radix-16 kernel
     try:
         be.apply_filter(d_p, k, fs, n_col)
     finally:
@@ -208,6 +208,117 @@ def test_weight_and_filter_random_sizes(be, oracle, seed):
     be.free(d_q)
     assert np.array_equal(band[first:first + count].view(np.uint32), got[first:first + count].view(np.uint32))
     assert np.array_equal(band[:first], p[:first]) and np.array_equal(band[first + count:], p[first + count:])
+
+
+@pytest.fixture(scope="module")
+def be_async():
+    """a ctx whose calls only enqueue (stage fusion is ignored under PARIS_HIP_CTX_SYNCHRONOUS)"""
+    b = B.set_device(B.get_devices()[0], synchronous=False)
+    yield b
+    b.close()
+
+
+def stage_constants(det):
+    """h_min, v_min, d_sd as paris::weight derives them (src/weighting.cpp:37-42), in fp32"""
+    f = np.float32
+    h_min = f(det.delta_s) * f(det.l_px_row) - (f(det.n_row) * f(det.l_px_row)) / f(2)
+    v_min = f(det.delta_t) * f(det.l_px_col) - (f(det.n_col) * f(det.l_px_col)) / f(2)
+    return float(h_min), float(v_min), float(abs(f(det.d_so)) + abs(f(det.d_od)))
+
+
+@pytest.mark.parametrize("n_row,n_col,fs_override", [(512, 37, 0), (1000, 9, 0), (1024, 16, 0), (2048, 12, 0), (3000, 5, 0),
+                                                     (4097, 3, 0), (1500, 6, 2048), (700, 4, 1024)])
+def test_fused_weight_filter_equals_the_two_stages(be_async, oracle, n_row, n_col, fs_override):
+    """weighting rides along in the row filter's load. One launch must give the bits of the two launches
+    (weight kernel, then the same filter kernel without weighting) -- through the held-back weight() + apply_filter() pair
+    (stage fusion) and through the explicit paris_hip_weight_filter_rows -- and stay within the filter tolerance of the CPU
+    oracle. fs_override: a filter length below 2 * n_row (dim_x > N/2: the kernel variant without the zero-padding shortcuts).
+    The half-precision store variant must equal the fp32 result rounded to half, and leave the fp32 rows alone."""
+    be = be_async
+    g = (n_row, n_col, 0.127, 0.2, 2.5, -1.25, 300.0, 250.0, 1.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    fs = fs_override or oracle.filter_size(n_row)
+    p = (oracle.lcg_projection(n_row, n_col, 3) - np.float32(0.3)) * np.float32(17.0)
+    h_min, v_min, d_sd = stage_constants(det)
+    k = be.make_filter(fs, det.l_px_row)
+
+    be.set_stage_fusion(False)
+    d_a = to_device(be, p)
+    be.weight(d_a, h_min, v_min, d_sd, det.l_px_row, det.l_px_col)
+    got_w = to_host(be, d_a)
+    want_w = oracle.weight(p.copy(), odet)
+    assert np.array_equal(got_w.view(np.uint32), want_w.view(np.uint32))
+    be.apply_filter(d_a, k, fs, n_col)
+    two = to_host(be, d_a)
+    want = oracle.apply_filter(want_w.copy(), oracle.make_filter(fs, det.l_px_row), fs)
+    assert np.max(np.abs(two - want)) <= FILTER_TOL * np.abs(want).max() and rel_l2(two, want) <= FILTER_TOL
+
+    be.set_stage_fusion(True)
+    try:
+        d_b = to_device(be, p)
+        be.weight(d_b, h_min, v_min, d_sd, det.l_px_row, det.l_px_col)   # held back
+        be.apply_filter(d_b, k, fs, n_col)                                 # one launch
+        one = to_host(be, d_b)
+        assert np.array_equal(one.view(np.uint32), two.view(np.uint32))
+        # a held-back weighting that no filter picks up is run by whatever looks at the projection next
+        d_c = to_device(be, p)
+        be.weight(d_c, h_min, v_min, d_sd, det.l_px_row, det.l_px_col)
+        assert np.array_equal(to_host(be, d_c).view(np.uint32), want_w.view(np.uint32))
+        # ... and a filter call on OTHER rows does not swallow it
+        if n_col >= 4:
+            d_d = to_device(be, p)
+            B._lib.check(be._L.paris_hip_weight_rows(be._ctx, d_d.ptr, d_d.pitch, n_row, n_col, 0, 2, h_min, v_min, d_sd, det.l_px_row,
+                                                    det.l_px_col), "weight_rows")
+            B._lib.check(be._L.paris_hip_apply_filter(be._ctx, d_d.ptr + 2 * d_d.pitch, d_d.pitch, n_row, 2, k.ptr, fs, 2), "apply_filter")
+            mixed = to_host(be, d_d)
+            assert np.array_equal(mixed[:2].view(np.uint32), want_w[:2].view(np.uint32))       # weighted only
+            raw_f = oracle.apply_filter(p[2:4].copy(), oracle.make_filter(fs, det.l_px_row), fs)
+            assert np.max(np.abs(mixed[2:4] - raw_f)) <= FILTER_TOL * np.abs(raw_f).max()        # filtered only
+            assert np.array_equal(mixed[4:], p[4:])
+            be.free(d_d)
+        be.free(d_b)
+        be.free(d_c)
+    finally:
+        be.set_stage_fusion(False)
+
+    # explicit one-launch entry point, a band of whole row pairs; rows outside stay raw
+    first = 2 * (n_col // 4)
+    count = min(n_col - first, 6)
+    d_e = to_device(be, p)
+    be.weight_filter_rows(d_e, first, count, h_min, v_min, d_sd, det.l_px_row, det.l_px_col, k, fs)
+    band = to_host(be, d_e)
+    assert np.array_equal(band[first:first + count].view(np.uint32), two[first:first + count].view(np.uint32))
+    assert np.array_equal(band[:first], p[:first]) and np.array_equal(band[first + count:], p[first + count:])
+    # half-precision store
+    import torch
+    d_f = to_device(be, p)
+    half = torch.full((n_col, n_row + 3), -3.0, dtype=torch.float16, device="cuda:%d" % be.device)
+    be.weight_filter_rows(d_f, 0, n_col, h_min, v_min, d_sd, det.l_px_row, det.l_px_col, k, fs, half.data_ptr(), half.stride(0) * 2)
+    be.synchronize()
+    h = half.cpu().numpy()
+    assert np.array_equal(h[:, :n_row].view(np.uint16), two.astype(np.float16).view(np.uint16))
+    assert np.all(h[:, n_row:] == np.float16(-3.0))
+    assert np.array_equal(to_host(be, d_f), p)  # the fp32 rows were only read
+    for d in (d_a, d_e, d_f):
+        be.free(d)
+    be.free(k)
+
+
+def test_fused_filter_needs_a_library_filter(be_async, oracle):
+    """the one-launch entry point refuses a K it has no permuted copy of, and lengths below 1024 (the caller runs two stages)"""
+    be = be_async
+    det = B.DetectorGeometry(64, 8, 0.2, 0.2, 0, 0, 100, 200, 1.0)
+    d_p = to_device(be, oracle.lcg_projection(64, 8, 1))
+    k = be.make_filter(128, 0.2)
+    with pytest.raises(B.ParisHipError):
+        be.weight_filter_rows(d_p, 0, 8, -6.4, -0.8, 300.0, 0.2, 0.2, k, 128)
+    k2 = be.make_filter(1024, 0.2)
+    fake = B.FilterBuffer(k.ptr, 1024, be)  # a buffer that is not a 1024-point K of this ctx
+    with pytest.raises(B.ParisHipError):
+        be.weight_filter_rows(d_p, 0, 8, -6.4, -0.8, 300.0, 0.2, 0.2, fake, 1024)
+    be.free(d_p)
+    be.free(k)
+    be.free(k2)
 
 
 def test_filter_wrapper_and_golden(be, oracle, kat_golden):

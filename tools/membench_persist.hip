@@ -42,6 +42,28 @@ __global__ void __launch_bounds__(256) tile_today(float* vol, uint32_t dx, uint3
     }
 }
 
+// today's z-walk with 64 lanes along x: tile 256 x 4 x TZ (1 KiB contiguous per wave and slice)
+template <int TZ>
+__global__ void __launch_bounds__(256) tile_xl64(float* vol, uint32_t dx, uint32_t dy, uint32_t dz)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t ntx = dx / 256, nty = dy / 4, ntz = dz / TZ;
+    const uint32_t per = (ntx * nty * ntz) / 8u;
+    uint32_t b = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
+    const uint32_t bx = b % ntx; b /= ntx;
+    const uint32_t by = b % nty; const uint32_t bz = b / nty;
+    const uint32_t k = bx * 256 + lane * 4u;
+    const uint32_t l = by * 4 + wave;
+    const size_t slice = (size_t)dx * dy;
+    float* vp = vol + ((size_t)bz * TZ * dy + l) * dx + k;
+    for(uint32_t mm = 0; mm + 1 < TZ; mm += 2)
+    {
+        v4f a = ld(vp + mm * slice), c = ld(vp + (mm + 1) * slice);
+        a += 1.f; c += 1.f;
+        st(vp + mm * slice, a); st(vp + (mm + 1) * slice, c);
+    }
+}
+
 // linear sweep, one 16-byte load + store per thread, 64 lanes along x (the 6.5 TB/s ceiling)
 __global__ void __launch_bounds__(256) linear(float* vol)
 {
@@ -53,7 +75,7 @@ __global__ void __launch_bounds__(256) linear(float* vol)
 // 64: tile 256 x 4). XCD k owns a band of rows inside each pass; a pass covers 8 bands; passes = dy / (8 * band rows).
 // IF slices in flight per lane. S > 0: after every S slices a workgroup adds 1 to its XCD's counter and waits (bounded)
 // until every workgroup of the XCD has finished chunk c - LAG.
-template <int XL, int IF, int S, int LAG>
+template <int XL, int IF, int S, int LAG, int SLEEP = 2>
 __global__ void __launch_bounds__(256) persist(float* vol, uint32_t dx, uint32_t dy, uint32_t dz, uint32_t wpx,
                                                unsigned* counters, unsigned epoch_base)
 {
@@ -101,7 +123,7 @@ __global__ void __launch_bounds__(256) persist(float* vol, uint32_t dx, uint32_t
                         {
                             if((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0)
                                 break;
-                            __builtin_amdgcn_s_sleep(2);
+                            __builtin_amdgcn_s_sleep(SLEEP);
                         }
                     }
                 }
@@ -124,15 +146,22 @@ int main(int argc, char** argv)
     const double gb = 2.0 * n * 4 / 1e9;
     std::vector<Variant> vs;
     vs.push_back({"today: tile 64x16x16, 2 in flight", [=] { tile_today<16><<<(dx / 64) * (dy / 16) * (dz / 16), 256>>>(a, dx, dy, dz); }, {}});
+    vs.push_back({"z-walk tile 256x4x16, 2 in flight", [=] { tile_xl64<16><<<(dx / 256) * (dy / 4) * (dz / 16), 256>>>(a, dx, dy, dz); }, {}});
+    vs.push_back({"z-walk tile 256x4x8, 2 in flight", [=] { tile_xl64<8><<<(dx / 256) * (dy / 4) * (dz / 8), 256>>>(a, dx, dy, dz); }, {}});
+    vs.push_back({"z-walk tile 256x4x32, 2 in flight", [=] { tile_xl64<32><<<(dx / 256) * (dy / 4) * (dz / 32), 256>>>(a, dx, dy, dz); }, {}});
     vs.push_back({"linear depth 1 (ceiling)", [=] { linear<<<(unsigned)(n / 1024), 256>>>(a); }, {}});
 #define ADDP(XL, IF, WPX) vs.push_back({"persist XL" #XL " IF" #IF " wpx" #WPX " no pacing", [=] { persist<XL, IF, 0, 1><<<8 * WPX, 256>>>(a, dx, dy, dz, WPX, cnt, 0); }, {}})
     ADDP(16, 2, 256); ADDP(16, 4, 256); ADDP(64, 2, 256); ADDP(64, 4, 256); ADDP(16, 2, 128); ADDP(16, 4, 128); ADDP(64, 4, 128); ADDP(16, 8, 64);
     // paced variants: each gets its own counter block so epochs never mix
     std::vector<unsigned*> cbs;
+#define ADDG(XL, IF, S, LAG, WPX, SLEEP) { unsigned* c; CK(hipMalloc(&c, 8 * 64 * 4)); CK(hipMemset(c, 0, 8 * 64 * 4)); cbs.push_back(c); \
+        unsigned* ep = new unsigned(0); const unsigned chunks = (2048u / (8u * ((WPX / (dx / (XL * 4u))) * (256u / XL)))) * (dz / S); \
+        vs.push_back({"persist XL" #XL " IF" #IF " wpx" #WPX " pace S" #S " lag" #LAG " sleep" #SLEEP, [=] { persist<XL, IF, S, LAG, SLEEP><<<8 * WPX, 256>>>(a, dx, dy, dz, WPX, c, *ep); *ep += chunks * WPX; }, {}}); }
 #define ADDS(XL, IF, S, LAG, WPX) { unsigned* c; CK(hipMalloc(&c, 8 * 64 * 4)); CK(hipMemset(c, 0, 8 * 64 * 4)); cbs.push_back(c); \
         unsigned* ep = new unsigned(0); const unsigned chunks = (2048u / (8u * ((WPX / (dx / (XL * 4u))) * (256u / XL)))) * (dz / S); \
         vs.push_back({"persist XL" #XL " IF" #IF " wpx" #WPX " pace S" #S " lag" #LAG, [=] { persist<XL, IF, S, LAG><<<8 * WPX, 256>>>(a, dx, dy, dz, WPX, c, *ep); *ep += chunks * WPX; }, {}}); }
     ADDS(16, 2, 2, 1, 256); ADDS(16, 2, 4, 1, 256); ADDS(16, 2, 8, 1, 256); ADDS(16, 2, 16, 1, 256); ADDS(16, 2, 4, 2, 256);
+    ADDG(16, 2, 16, 2, 256, 32); ADDG(16, 2, 32, 2, 256, 32); ADDG(64, 2, 32, 2, 256, 32); ADDG(64, 4, 32, 4, 128, 64); ADDG(16, 2, 64, 2, 256, 64);
     ADDS(64, 2, 4, 1, 256); ADDS(64, 2, 8, 1, 256); ADDS(16, 4, 4, 1, 256); ADDS(16, 4, 8, 1, 256); ADDS(16, 4, 8, 1, 128);
     for(auto& v : vs) v.f();
     CK(hipDeviceSynchronize());

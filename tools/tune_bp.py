@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=2048)
     ap.add_argument("--slices", type=int, default=256)
+    ap.add_argument("--vol", type=int, default=0, help="volume edge when it differs from the detector width (config 1: --n 512 --vol 256)")
     ap.add_argument("--vx", default="4,2,1")
     ap.add_argument("--unroll", default="1,2,4")
     ap.add_argument("--tz", default="16,32,64")
@@ -31,15 +32,17 @@ def main():
     n = args.n
     det = B.DetectorGeometry(n, n, 0.2, 0.2, 0, 0, 500, 500, 360.0 / 1440)
     nat = B.calculate_volume_geometry(det)
-    vg = B.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
+    nv = args.vol or n
+    l_vx = float(np.float32(nat.l_vx_x) * np.float32(n) / np.float32(nv))
+    vg = B.VolumeGeometry(nv, nv, nv, l_vx, l_vx, l_vx)
     be = B.Backend(0, synchronous=False)
     rng = np.random.default_rng(1)
     h = B.Projection(rng.random((n, n), dtype=np.float32), n, n)
     d_p = B.load(be, h)
-    d_v = be.make_volume_device(n, n, args.slices)
-    z_first = (n - args.slices) // 2
+    d_v = be.make_volume_device(nv, nv, args.slices)
+    z_first = (nv - args.slices) // 2
     angles = [int(a) for a in args.angles.split(",")]
-    voxels = float(n) * n * args.slices
+    voxels = float(nv) * nv * args.slices
     results = []
     if args.fused:
         import ctypes as C
