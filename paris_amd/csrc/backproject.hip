@@ -907,6 +907,8 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         if(skip)
             break;
         fp.n_proj = n;
+        if(ctx->bp_lds_bytes == 0u) // the fused kernel runs 4 workgroups per CU: a 32 KiB box budget (tools/tune_bp.py --fused: +1.7 %)
+            fp.g.lds_floats = 32u * 1024u / sizeof(float);
         fp.proj_stride = static_cast<uint32_t>(p_stride_bytes / px);
         // fill_params decided the 4-pixel staging from the first projection's address: every later base must be as aligned
         if(n > 1 && p_stride_bytes % (4u * px) != 0)
@@ -920,7 +922,7 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         const size_t ev = timed ? static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size()) : 0u;
         if(timed)
             PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
-        paris_hip_bp_launch_fused(&fp, fused_vx, tz16 ? 16 : 8, nt, fd, ctx->stream);
+        paris_hip_bp_launch_fused(&fp, fused_vx, (fused_vx == 1 && ctx->bp_tz == 32u) ? 32 : (tz16 ? 16 : 8), nt, fd, ctx->stream);
         if(timed)
             PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
         ++ctx->bp_launches;

@@ -20,7 +20,7 @@ namespace
 #define PARIS_FUSED_WAVES 3
 #endif
     template <int VX, int TZ, bool NT, bool FD>
-    __global__ void __launch_bounds__(256, PARIS_FUSED_WAVES + (VX == 2 ? 1 : VX == 1 ? 4 : 0) + (TZ == 8 ? 1 : 0)) bp_fused_kernel(const FusedParams fp)
+    __global__ void __launch_bounds__(256, PARIS_FUSED_WAVES + (VX == 2 ? 1 : VX == 1 ? (TZ == 32 ? 1 : 4) : 0) + (TZ == 8 ? 1 : 0)) bp_fused_kernel(const FusedParams fp)
     {
         extern __shared__ __attribute__((aligned(16))) float lds[];
         BpParams g = fp.g;
@@ -140,7 +140,9 @@ namespace
 void paris_hip_bp_launch_fused(const void* fused_params, int vx, int tz, bool nt, bool fd, hipStream_t stream)
 {
     FusedParams fp = *static_cast<const FusedParams*>(fused_params);
-    if(vx == 1) // tz 8 is not built for this width
+    if(vx == 1 && tz == 32) // one column per lane, 32 slices deep: half the column setups per voxel-update of <2, 16>
+        launch_fused_flags<1, 32>(fp, nt, fd, stream);
+    else if(vx == 1) // tz 8 is not built for this width
         launch_fused_flags<1, 16>(fp, nt, fd, stream);
     else if(vx == 2 && tz == 8)
         launch_fused_flags<2, 8>(fp, nt, fd, stream);

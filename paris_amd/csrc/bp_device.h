@@ -222,7 +222,19 @@ namespace
                                             uint32_t m0, uint32_t m1, uint32_t lane, uint32_t box_floats)
     {
         const uint32_t ci = lane & 3u;
-        const ColConst c = column_constants<false>(g, g.k_off + ((ci & 1u) ? k1 : k0), g.l_off + ((ci & 2u) ? l1 : l0));
+        // The box only has to be right for speed (a tap outside it takes the global path, and whether a column may skip the
+        // per-tap check is decided from the exact coordinates in make_column), so the corner rays are evaluated with the
+        // hardware reciprocal instead of three IEEE divisions: ~2e-7 relative, far inside the one pixel of slack below.
+        ColConst c;
+        {
+            const float x_k = g.x_base + static_cast<float>(g.k_off + ((ci & 1u) ? k1 : k0)) * g.l_vx_x;
+            const float y_l = g.y_base + static_cast<float>(g.l_off + ((ci & 2u) ? l1 : l0)) * g.l_vx_y;
+            const float s = x_k * g.cos_phi + y_l * g.sin_phi;
+            const float t = -x_k * g.sin_phi + y_l * g.cos_phi;
+            c.factor = g.d_sd * __builtin_amdgcn_rcpf(s + g.d_so);
+            c.h = ((t * c.factor) - g.min_h) * g.rcp_l_px_x - (1.f / 2.f);
+            c.u = 0.f;
+        }
         float hmin = c.h, hmax = c.h, fmin = c.factor, fmax = c.factor;
 #pragma unroll
         for(int m = 1; m <= 2; m <<= 1)
@@ -233,7 +245,7 @@ namespace
             fmax = fmaxf(fmax, __shfl_xor(fmax, m));
         }
         const float z_c = g.z_base + static_cast<float>(g.m_off + ((ci & 1u) ? m1 : m0)) * g.l_vx_z;
-        const float v_c = v_coordinate<false>(g, z_c, (ci & 2u) ? fmax : fmin);
+        const float v_c = ((z_c * ((ci & 2u) ? fmax : fmin)) - g.min_v) * g.rcp_l_px_y - (1.f / 2.f);
         float vmin = v_c, vmax = v_c;
 #pragma unroll
         for(int m = 1; m <= 2; m <<= 1)

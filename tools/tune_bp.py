@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--order", default="0,1,5")
     ap.add_argument("--fused", default="", help="fused kernel: projections per launch, e.g. 4,8,16 (uses --tz 8|16, --lds)")
+    ap.add_argument("--fused-vx", default="0", help="lane widths of the fused kernel to try (0 = default 2; 1 with --tz 32: 32-slice tiles)")
     ap.add_argument("--slice", default="", help="slice kernel shapes, e.g. 16x4,8x2 (empty: tile kernel)")
     ap.add_argument("--nt", default="0,1")
     args = ap.parse_args()
@@ -51,8 +52,8 @@ def main():
         stack = be.make_projection_device(n, n * nmax)
         hs = B.Projection(rng.random((n * nmax, n), dtype=np.float32), n, n * nmax)
         be.copy_h2d(hs, stack)
-        for P, tz, lds in itertools.product(*[[int(x) for x in s.split(",")] for s in (args.fused, args.tz, args.lds)]):
-            be.set_backproject_tuning(0, 0, tz, lds)
+        for P, tz, lds, vx in itertools.product(*[[int(x) for x in s.split(",")] for s in (args.fused, args.tz, args.lds, args.fused_vx)]):
+            be.set_backproject_tuning(vx, 0, tz, lds)
             sc = [B.stage_angle(det, 4 * (a + 3 * i)) for i, a in enumerate(range(P))]
             ms = []
             for rep in range(args.reps + 1):
@@ -62,7 +63,7 @@ def main():
                 if rep > 0:
                     ms.append(t)
             avg = sum(ms) / len(ms)
-            r = dict(kernel="fused", P=P, tz=tz, lds=lds, ms=avg, ms_per_proj=avg / P, gvox=voxels * P / avg / 1e6,
+            r = dict(kernel="fused", P=P, tz=tz, lds=lds, vx=vx, ms=avg, ms_per_proj=avg / P, gvox=voxels * P / avg / 1e6,
                      hbm_gbs=(8.0 / P) * voxels * P / avg / 1e6)
             results.append(r)
             print(json.dumps(r), flush=True)
