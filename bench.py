@@ -220,6 +220,10 @@ def main():
                     "detector rows its z-slab can read (paris_hip_slab_row_band; the whole detector at N = 1); 0: all rows")
     ap.add_argument("--stage-fusion", type=int, default=1, help="1 (default): weight + filter in one launch (paris_hip_set_stage_fusion); "
                     "0: one launch per call")
+    ap.add_argument("--filter-shard", type=int, default=0, help="N > 1 (SURVEY f4, second half): 1 = rank r weights and filters "
+                    "projections r, r + N, ... once for everybody and the ranks exchange the rows of each other's detector bands per "
+                    "group of N projections (paris_amd.sharding.exchange_filtered, RCCL point-to-point batch). Off by default: it "
+                    "costs more than it removes (profiles/r02_rank_breakdown_c4_c5.txt)")
     ap.add_argument("--graph", type=int, default=0, help="1: every timed step is captured once into a hipGraph (torch.cuda.graph on "
                     "the bench stream: copy + weight/filter + backproject of all its projections, angles baked in) before the timed "
                     "region and replayed inside it -- for the launch-bound small configurations; kernel times then come from a "
@@ -286,7 +290,7 @@ def main():
     n_row, n_col, n_proj = w["n_row"], w["n_col"], w["n_proj"]
     batch = args.batch if args.batch > 0 else -(-n_proj // max(1, args.steps))
     gen = torch.Generator(device=dev)
-    gen.manual_seed(12345 + rank)
+    gen.manual_seed(12345)  # every rank holds the same projection stack (north star: "each GPU holding the full projection stack")
     fb = max(2, min(32, args.fused_batch))
     nb = max(16, fb)  # work slots and distinct raw frames; a step cycles through them (stream order makes the reuse safe)
     raw = torch.rand((nb, n_col, n_row), generator=gen, device=dev, dtype=torch.float32)
@@ -306,7 +310,39 @@ def main():
 
     launched = []  # projection index of every single-projection backprojection call, in call order
 
+    shard = bool(args.filter_shard) and world > 1
+    if shard:
+        if f16:
+            raise SystemExit("bench.py --filter-shard: fp32 workloads only")
+        on_device = args.dist_backend == "nccl"
+        slabs = [sharding.slab_of_task(info, t) for t in range(world)]
+        bands = [B.slab_row_band(det, vol_geo, out_geo.dim_x, out_geo.dim_y, slabs[t][1], slabs[t][0], roi) if args.row_band else (0, n_col)
+                 for t in range(world)]
+        shard_recv = torch.zeros((world, n_col, n_row), device=dev, dtype=torch.float32)
+        recv_projs = [be.wrap_projection(shard_recv[q].data_ptr(), pitch, n_row, n_col, owner=shard_recv) for q in range(world)]
+
+    def sharded_step(first_idx, cnt):
+        for j0 in range(0, cnt, world):
+            j = j0 + rank  # this rank's projection of the group: weighted and filtered here, once, for every rank
+            mine = None
+            if j < cnt:
+                p = projs[0]
+                p.idx = (first_idx + j) % n_proj
+                work[0].copy_(raw[j % nb], non_blocking=True)   # the whole frame: every rank needs other rows of it
+                B.weight_rows(be, p, det, 0, n_col)
+                B.filter_rows(be, p, det, 0, n_col)
+                mine = work[0]
+            sharding.exchange_filtered(dist, mine, [shard_recv[q] for q in range(world)], bands, rank, world, on_device=on_device)
+            for q in range(world):
+                if j0 + q < cnt:
+                    rp = recv_projs[q]
+                    rp.idx = (first_idx + j0 + q) % n_proj
+                    B.backproject(be, rp, d_vol, z_first, det, vol_geo, False, roi is not None, roi)
+                    launched.append(rp.idx)
+
     def step(first_idx, count=None):
+        if shard:
+            return sharded_step(first_idx, batch if count is None else count)
         for j in range(batch if count is None else count):
             b = j % nb
             p = projs[b]
@@ -452,17 +488,20 @@ def main():
         barrier()
         torch.cuda.synchronize()
         tg0 = time.perf_counter()
-        res = sharding.final_gather(dist, vol, info, rank, world, full=(args.final_gather == "slabs"), on_device=on_device)
-        torch.cuda.synchronize()
-        barrier()
-        tg = max_over_ranks(time.perf_counter() - tg0)
-        gather = {"mode": args.final_gather, "seconds": tg, "backend": "rccl" if on_device else args.dist_backend,
-                  "rccl_ranks_seen": dist.get_world_size(), "slab_checksums": res["checksums"],
-                  "checksum_of_checksums": res["checksum_of_checksums"]}
-        if res.get("gathered_bytes"):
-            gather["gathered_bytes"] = res["gathered_bytes"]
-            gather["GBps_into_rank0"] = res["gathered_bytes"] / tg / 1e9
-            gather["gathered_matches_checksums"] = res.get("gathered_matches_checksums")
+        try:
+            res = sharding.final_gather(dist, vol, info, rank, world, full=(args.final_gather == "slabs"), on_device=on_device)
+            torch.cuda.synchronize()
+            barrier()
+            tg = max_over_ranks(time.perf_counter() - tg0)
+            gather = {"mode": args.final_gather, "seconds": tg, "backend": "rccl" if on_device else args.dist_backend,
+                      "rccl_ranks_seen": dist.get_world_size(), "slab_checksums": res["checksums"],
+                      "checksum_of_checksums": res["checksum_of_checksums"]}
+            if res.get("gathered_bytes"):
+                gather["gathered_bytes"] = res["gathered_bytes"]
+                gather["GBps_into_rank0"] = res["gathered_bytes"] / tg / 1e9
+                gather["gathered_matches_checksums"] = res.get("gathered_matches_checksums")
+        except RuntimeError as e:  # the headline was measured before this point: report the failure instead of losing the line
+            gather = {"mode": args.final_gather, "error": str(e)[:500]}
 
     voxels_rank = float(z_count) * out_geo.dim_x * out_geo.dim_y
     voxels_all = float(out_geo.dim_z) * out_geo.dim_x * out_geo.dim_y
@@ -501,6 +540,7 @@ def main():
                 "parallelism": "z-slab per GPU, no collective on the data path",
                 "stage_fusion": bool(args.stage_fusion),
                 "hip_graph": bool(args.graph),
+                "filter_shard": shard,
                 "backproject_kernel_ms": avg_ms,
                 "backproject_kernel_ms_min": min(kernel_ms) if kernel_ms else 0.0,
                 "backproject_kernel_ms_max": max(kernel_ms) if kernel_ms else 0.0,

@@ -127,3 +127,48 @@ def final_gather(dist, slab, info, rank, world, full=False, on_device=True, dst=
         res["gathered_matches_checksums"] = bool(ok)
         res["volume"] = recv, counts  # slabs in task order (padded) and their true depths
     return res
+
+
+# ---- f4, second half: filter sharding (motivated by src/main.cpp:93-105: every device weights and filters
+# every projection again). Rank r weights and filters projections r, r + N, r + 2N, ... once, for everybody; the ranks
+# then exchange, per group of N projections, exactly the detector rows each of them needs (its slab's row band): an
+# all-to-all of band-cropped frames over RCCL. Off by default: with the row band on, weighting + filtering is ~1 % of a rank's
+# step and the exchange costs more than it removes (profiles/r02_rank_breakdown_c4_c5.txt).
+
+def owner_of_projection(position, world):
+    """rank that weights and filters the projection at `position` of the job (round-robin)"""
+    return position % world
+
+
+def exchange_filtered(dist, mine, recv, bands, rank, world, on_device=True):
+    """One group of `world` projections: `mine` is this rank's filtered frame (n_col x n_row, all rows filtered; None when the
+    group is short and this rank has none), `recv[q]` a full-size frame buffer that receives, in the rows of this rank's band
+    bands[rank] = (first, count), the same rows of rank q's frame; rows outside the band are not touched. The exchange is
+    an all-to-all of band-cropped frames written as one batch of point-to-point sends and receives (what RCCL's all-to-all
+    is underneath; unlike all_to_all the batch also runs on gloo): rank r sends to q the rows of q's band, (N - 1) x band
+    bytes in and out per rank and group, nothing larger. on_device=False (rehearsal with several ranks on one GPU over gloo):
+    the tensors go through host memory."""
+    import torch
+    my_first, my_count = bands[rank]
+    if mine is None:
+        mine = torch.zeros_like(recv[0])
+    src = mine if on_device else mine.detach().cpu()
+    landing = {}
+    ops = []
+    for q in range(world):
+        q_first, q_count = bands[q]
+        if q == rank:
+            recv[q][my_first:my_first + my_count].copy_(mine[my_first:my_first + my_count])
+            continue
+        if q_count:
+            ops.append(dist.P2POp(dist.isend, src[q_first:q_first + q_count], q))      # a row range: a contiguous view
+        if my_count:
+            dst = recv[q][my_first:my_first + my_count]
+            if not on_device:
+                dst = landing[q] = torch.empty(dst.shape, dtype=dst.dtype)
+            ops.append(dist.P2POp(dist.irecv, dst, q))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for q, host in landing.items():
+        recv[q][my_first:my_first + my_count].copy_(host)

@@ -79,3 +79,25 @@ def test_two_rank_rehearsal_gathers_slabs():
     fg = d["final_gather"]
     assert fg["mode"] == "slabs" and fg["gathered_matches_checksums"] is True
     assert fg["gathered_bytes"] == 4.0 * 256 * 256 * 128 and d["config"]["whole_job"] is False
+
+
+def test_two_rank_rehearsal_filter_sharding():
+    """f4, second half, through bench.py itself: two ranks on the one GPU (gloo), each filters every other projection, bands
+    are exchanged, the slab checksums equal those of the unsharded two-rank run (same projections, same volume)."""
+    def run(extra):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload",
+                            "c1", "--steps", "1", "--warmup", "0", "--batch", "7", "--dist-backend", "gloo", "--device", "0",
+                            "--fused-steps", "0"] + extra, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return last_json_line(r.stdout)
+    plain, sharded = run([]), run(["--filter-shard", "1"])
+    assert sharded["config"]["filter_shard"] is True and plain["config"]["filter_shard"] is False
+    # every rank holds the same synthetic stack, band rows filtered alone equal the same rows of a whole-frame filter bit for bit
+    # and the backprojection is bit-exact: the two runs must produce identical slabs
+    assert sharded["final_gather"]["slab_checksums"] == plain["final_gather"]["slab_checksums"]
+    assert len(sharded["final_gather"]["slab_checksums"]) == 2 and sharded["value"] > 0
+    assert sharded["roofline"]["launches_timed"] == 7
