@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--tz", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
+    ap.add_argument("--order", type=int, default=-1, help="workgroup -> tile order of the backprojection kernel (-1: the library's default)")
     ap.add_argument("--fused-steps", type=int, default=8, help="extra steps with the fused multi-projection kernel, "
                     "reported as fused_extension next to the headline (0 disables); the steps are spread over the circle")
     ap.add_argument("--fused-batch", type=int, default=16, help="projections per fused launch in fused_extension and "
@@ -284,6 +285,8 @@ def main():
     stream = None if mode == "private" else torch.cuda.current_stream(dev).cuda_stream
     be = B.Backend(dev_index, stream=stream, synchronous=False)
     be.set_backproject_tuning(args.vx, args.unroll, args.tz, args.lds_bytes)
+    if args.order >= 0:
+        be.set_backproject_order(args.order, -1)
     # paris::weight is held back and rides along in the load of the paris::filter call that follows: one launch for the pair
     be.set_stage_fusion(bool(args.stage_fusion))
 
@@ -540,6 +543,7 @@ def main():
                 "parallelism": "z-slab per GPU, no collective on the data path",
                 "stage_fusion": bool(args.stage_fusion),
                 "hip_graph": bool(args.graph),
+                "volume_device_address": hex(vol.data_ptr()),
                 "filter_shard": shard,
                 "backproject_kernel_ms": avg_ms,
                 "backproject_kernel_ms_min": min(kernel_ms) if kernel_ms else 0.0,

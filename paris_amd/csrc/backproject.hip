@@ -328,6 +328,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + TY - 1u) / TY;
         g.ntz = (g.v_dim_z + g.tz - 1u) / g.tz;
+        g.zchunk = std::max(1u, 256u / std::max(1u, g.tz)); // order 12: chunks of 256 slices
         uint32_t blocks = grid_blocks(g);
         hipLaunchKernelGGL((bp_tile_kernel<VX, UNROLL, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, g);
     }
@@ -368,6 +369,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + TY - 1u) / TY;
         g.ntz = (g.v_dim_z + NW - 1u) / NW;
+        g.zchunk = std::max(1u, 256u / static_cast<uint32_t>(NW));
         uint32_t blocks = grid_blocks(g);
         const uint32_t lds_bytes = g.lds_floats * sizeof(float);
         if(lds_bytes > 64u * 1024u) // beyond the default dynamic-LDS limit (only with a raised box budget): per launch, cheap
@@ -505,10 +507,19 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
         skip = true;
         return PARIS_HIP_SUCCESS;
     }
-    // tile depth: 16 slices, 8 for planes of 1024^2 voxels and less (+2.5 % on the 1024^3 volume: shorter z-walks keep
-    // the concurrently touched slices of the smaller planes closer together; profiles/r02_tune_bp_c2.jsonl)
-    const bool small_plane = static_cast<uint64_t>(v_dim_x) * v_dim_y <= (1ull << 20) && static_cast<uint64_t>(v_dim_x) * v_dim_y > (1ull << 18);
-    const uint32_t tz = ctx->bp_tz ? ctx->bp_tz : (small_plane ? 8u : TZ_DEFAULT);
+    // Tile depth and workgroup -> tile order by volume shape (tools/tune_bp.py and interleaved A/B of bench.py steps,
+    // profiles/r02_tune_bp_*.jsonl, profiles/r02_ab_tile_order.txt; bare access patterns: tools/membench.hip,
+    // profiles/r02_membench.txt). The volume stream wants a compact, sliding set of concurrently touched addresses: with a y band
+    // per XCD swept x -> z -> y (order 8) the set shrinks with the tile depth (bare: 6.03 / 6.25 / 6.35 / 6.5 TB/s at 16 / 8 / 4 / 2
+    // slices, against 6.67 for a linear sweep and 5.9 for the XCD-contiguous order 5 at 16), while the column setup a tile pays
+    // grows as 1 / depth and the detector rows an XCD reads grow with the depth it sweeps. Planes beyond 1024^2: order 12 (order 8
+    // in chunks of 256 slices, so the detector band of a chunk stays in the XCD's L2) -- with 8-slice tiles for slabs up to 512
+    // slices (2048 x 2048 x 256: 1.447 against 1.491 ms inside bench.py's step, +3 %), with 16-slice tiles for deeper volumes
+    // (2048^3: +0.2 %; 8-slice tiles are +1.1 % on one device and -0.4 % on another there). Planes up to 1024^2: order 5 with 8-slice
+    // tiles (+2.5 %; the band orders lose 3 %), up to 512^2 with 16-slice tiles.
+    const uint64_t plane = static_cast<uint64_t>(v_dim_x) * v_dim_y;
+    const uint32_t tz_auto = plane > (1ull << 20) ? (v_dim_z <= 512u ? 8u : TZ_DEFAULT) : (plane > (1ull << 18) ? 8u : TZ_DEFAULT);
+    const uint32_t tz = ctx->bp_tz ? ctx->bp_tz : tz_auto;
     {
         // the 1-D grid must hold every tile (narrowest tile: 64 x 4 x tz)
         const uint64_t tiles = static_cast<uint64_t>((v_dim_x + 63u) / 64u) * ((v_dim_y + 3u) / 4u) * ((v_dim_z + std::min(tz, 8u) - 1u) / std::min(tz, 8u));
@@ -559,9 +570,8 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     g.p_dim_y_f = static_cast<float>(p_dim_y);
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
     g.tz = tz;
-    // default mapping: a contiguous run of tiles per XCD (best or within 0.4 % of the best on 1024^3 ... 2048^3 and slabs;
-    // the y-band mapping 8 ties at 2048 rows and loses 12 % at 1024: tools/ab_bp.py, tools/tune_bp.py)
-    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : 5u;
+    // default mapping: see the tile depth above (a y band per XCD beyond 1024^2 planes, a contiguous run of tiles per XCD below)
+    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 12u : 5u);
     g.store_sc1 = ctx->bp_nt == 2 ? 1u : 0u;
     // 4-pixel staging needs every detector row to start 16-byte (half: 8-byte) aligned
     g.stage_vec4 = (ctx->bp_stage_vec4 != 0 && g.p_pitch % 4u == 0 && reinterpret_cast<uintptr_t>(d_p) % (4u * px) == 0)
@@ -961,7 +971,7 @@ extern "C" int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, in
 {
     if(int rc = paris_hip_flush_deferred(ctx))
         return rc;
-    if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5 || order == 8) || nontemporal < -1 || nontemporal > 2)
+    if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5 || order == 8 || order == 9 || order == 12) || nontemporal < -1 || nontemporal > 2)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_order = order;
     ctx->bp_nt = nontemporal < 0 ? 2 : nontemporal;

@@ -42,6 +42,7 @@ namespace
         uint32_t tz; // slices per tile
         uint32_t ntx, nty, ntz; // tiles per axis
         uint32_t order;         // workgroup -> tile mapping, see tile_of_block
+        uint32_t zchunk;        // order 12: z tiles per chunk
         uint32_t store_sc1;     // nontemporal stores also carry sc1 (write-through)
         uint32_t stage_vec4;    // detector rows may be staged 4 pixels at a time (base and pitch aligned)
     };
@@ -115,8 +116,10 @@ namespace
         const uint32_t total = g.ntx * g.nty * g.ntz;
         if(g.order == 5u)
             return ((total + 7u) / 8u) * 8u;
-        if(g.order == 8u)
+        if(g.order == 8u || g.order == 9u)
             return 8u * ((g.nty + 7u) / 8u) * g.ntx * g.ntz;
+        if(g.order == 12u)
+            return 8u * ((g.nty + 7u) / 8u) * g.ntx * g.zchunk * ((g.ntz + g.zchunk - 1u) / g.zchunk);
         return total;
     }
 
@@ -158,7 +161,9 @@ namespace
     //   0: x tiles fastest, then y, then z (XCD k keeps hitting the same x columns: slowest)
     //   1: z tiles fastest, then x, then y
     //   5: XCD k sweeps its own contiguous eighth of the (x, y, z) tile sequence
-    //   8: XCD k owns a band of y tiles; x fastest, then z, then y inside the band (fastest: tools/membench5.hip)
+    //   8: XCD k owns a band of y tiles; x fastest, then z, then y inside the band
+    //   9: XCD k owns a band of y tiles; x fastest, then y, then z inside the band
+    //  12: order 8 chunk by chunk of 256 slices (deep volumes)
     __device__ __forceinline__ bool tile_of_block(const BpParams& g, uint32_t b, uint32_t& bx, uint32_t& by, uint32_t& bz)
     {
         const uint32_t total = g.ntx * g.nty * g.ntz;
@@ -185,6 +190,40 @@ namespace
             const uint32_t yb = r / g.ntz;
             by = xcd * band + yb;
             return yb < band && by < g.nty;
+        }
+        if(g.order == 12u)
+        {
+            // order 8 applied to one chunk of zchunk z tiles after the other: XCD k owns the band k of y tiles; x runs fastest,
+            // then the z tile inside the chunk, then y inside the band, then the chunk. A chunk of 256 slices reads a detector
+            // band that stays in the XCD's L2 (the whole depth of a 2048^3 volume does not: every XCD would read every detector
+            // row for each of its y tiles), so the deep volume streams like eight 256-slice slabs.
+            const uint32_t band = (g.nty + 7u) / 8u;
+            const uint32_t zchunk = g.zchunk;
+            const uint32_t xcd = b % 8u;
+            uint32_t r = b / 8u;
+            bx = r % g.ntx;
+            r /= g.ntx;
+            const uint32_t zl = r % zchunk;
+            r /= zchunk;
+            const uint32_t yb = r % band;
+            bz = (r / band) * zchunk + zl;
+            by = xcd * band + yb;
+            return bz < g.ntz && by < g.nty;
+        }
+        if(g.order == 9u)
+        {
+            // XCD k owns the contiguous band k of y tiles; inside the band x runs fastest, then y, then the z tile: all eight
+            // XCDs work on the same slices at any time (one eighth of each slice each), so the chip touches tz slices at once
+            // instead of 8 x tz
+            const uint32_t band = (g.nty + 7u) / 8u;
+            const uint32_t xcd = b % 8u;
+            uint32_t r = b / 8u;
+            bx = r % g.ntx;
+            r /= g.ntx;
+            const uint32_t yb = r % band;
+            bz = r / band;
+            by = xcd * band + yb;
+            return bz < g.ntz && by < g.nty;
         }
         if(g.order == 5u)
         {
