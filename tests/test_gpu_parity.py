@@ -435,6 +435,41 @@ def test_backproject_every_kernel_shape_bit_exact(be, oracle, tuning):
     assert_bit_equal(got, want)
 
 
+@pytest.mark.parametrize("order", [0, 1, 5, 8, 9, 12])
+@pytest.mark.parametrize("tz,dims", [(8, (300, 150, 200)), (16, (70, 260, 136)), (3, (45, 40, 72))])
+def test_backproject_every_tile_order_bit_exact(be, oracle, order, tz, dims):
+    """Every workgroup -> tile mapping of the tile kernel and of the fused kernel (x / z fastest, a contiguous run per XCD,
+    a y band per XCD swept x -> z -> y, x -> y -> z, and in chunks of 256 slices) covers every voxel exactly once: volumes
+    whose tile counts are not multiples of 8 (the XCD count) in y, deeper than one 256-slice chunk at tile depth 8, with a
+    slab offset; bit-identical to the oracle through single launches and through one fused launch."""
+    g = (96, 80, 0.2, 0.25, -2.5, 1.25, 150, 250, 40.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    full_z = dims[0] + 20
+    vg = B.VolumeGeometry(dims[2], dims[1], full_z, nat.l_vx_x * 0.5, nat.l_vx_x * 0.35, nat.l_vx_x * 0.25)
+    ovg = oracle.VolumeGeometry(dims[2], dims[1], full_z, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    projs = [oracle.lcg_projection(96, 80, i) - np.float32(0.5) for i in range(3)]
+    want = oracle_backproject_all(oracle, projs, odet, ovg, dims, v_offset=13)
+    be.set_backproject_tuning(tz=tz)
+    be.set_backproject_order(order, -1)
+    try:
+        got = hip_backproject_all(be, projs, det, vg, dims, v_offset=13)
+        assert_bit_equal(got, want)
+        if tz in (8, 16):  # the fused kernel is built for these tile depths
+            stack = np.stack(projs)
+            d_stack = to_device(be, stack.reshape(3 * 80, 96))
+            d_v = be.make_volume_device(dims[2], dims[1], dims[0])
+            sc = [B.stage_angle(det, i) for i in range(3)]
+            be.backproject_batch(d_stack.ptr, d_stack.pitch, d_stack.pitch * 80, 3, 96, 80, d_v, 13, det, vg, False, None,
+                                 [s for s, _ in sc], [c for _, c in sc], det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
+            assert_bit_equal(volume_to_host(be, d_v), want)
+            be.free(d_v)
+            be.free(d_stack)
+    finally:
+        be.set_backproject_tuning()
+        be.set_backproject_order()
+
+
 @pytest.mark.parametrize("fast", [False, True])
 @pytest.mark.parametrize("vec", [False, True])
 def test_backproject_fast_division_and_staging_switches(be, oracle, kat_golden, fast, vec):
