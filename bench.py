@@ -79,8 +79,18 @@ def measured_traffic(w, world):
         except (OSError, ValueError):
             continue
         if world == 1 and d.get("workload", "").startswith(w["name"]):
-            best = (d["traffic_bytes_per_launch"], os.path.relpath(path, ROOT))
-    return best if best else (None, None)
+            best = (d["traffic_bytes_per_launch"], os.path.relpath(path, ROOT), d.get("kernel_source_sha16"))
+    return best if best else (None, None, None)
+
+
+def kernel_source_sha16():
+    """fingerprint of the backprojection kernel's sources (as tools/pmc_traffic.py records it)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("backproject.hip", "bp_device.h"):
+        with open(os.path.join(ROOT, "paris_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(w, budget_s):
@@ -515,7 +525,7 @@ def main():
     updates_all = voxels_all * batch * args.steps
 
     if rank == 0:
-        traffic, traffic_src = measured_traffic(w, world)
+        traffic, traffic_src, traffic_sha = measured_traffic(w, world)
         avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         algo_bytes = 8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col  # per launch: RMW of the slab + one projection pass
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -559,6 +569,9 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
+                # the counters come from a committed rocprofv3 --pmc run (they cannot be read inside this process): stale when the
+                # kernel's sources have changed since
+                "traffic_is_of_this_kernel": (traffic_sha == kernel_source_sha16()) if traffic is not None else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel": "bp_tile_kernel (one projection per launch, 8 B per voxel-update)",
                 "launches_timed": len(kernel_ms),

@@ -11,8 +11,21 @@ FETCH_SIZE counts exactly half the bytes of a wide coalesced streaming read, so 
 """
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha16():
+    """fingerprint of the backprojection kernel's sources: bench.py flags a traffic record taken with other sources as stale"""
+    h = hashlib.sha256()
+    for name in ("backproject.hip", "bp_device.h"):
+        with open(os.path.join(ROOT, "paris_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def values(d, counter):
@@ -28,6 +41,7 @@ def main():
                  "hbm_bytes": a * 2048 + b * 1024} for a, b in zip(fetch, write)]
     out = {"workload": workload, "kernel": "bp_tile_kernel, one projection per launch", "launches": launches,
            "traffic_bytes_per_launch": sum(l["hbm_bytes"] for l in launches) / len(launches),
+           "kernel_source_sha16": kernel_source_sha16(),
            "note": "FETCH_SIZE x 1024 x 2 (gfx950 half-count of wide streaming reads) + WRITE_SIZE x 1024"}
     json.dump(out, open(out_path, "w"), indent=1)
     print(out["traffic_bytes_per_launch"])
