@@ -656,7 +656,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
     if(timed)
         PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
     ++ctx->bp_launches;
-    if(int rc = paris_hip_note_projection_use(ctx, d_p))
+    if(int rc = paris_hip_note_projection_use(ctx, d_p, p_pitch * p_dim_y))
         return rc;
     return paris_hip_finish(ctx);
 }
@@ -743,7 +743,7 @@ static int defer_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitc
     char* slot = reinterpret_cast<char*>(ctx->defer_ring) + ctx->defer_pitch * p_dim_y * ctx->defer_count;
     PARIS_HIP_TRY(hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * sizeof(float), p_dim_y,
                                    hipMemcpyDeviceToDevice, ctx->stream));
-    if(int rc = paris_hip_note_projection_use(ctx, d_p)) // the snapshot copy is the last reader of the caller's buffer
+    if(int rc = paris_hip_note_projection_use(ctx, d_p, p_pitch * p_dim_y)) // the snapshot copy is the last reader of the caller's buffer
         return rc;
     ctx->defer_sin[ctx->defer_count] = sin_phi;
     ctx->defer_cos[ctx->defer_count] = cos_phi;
@@ -826,7 +826,7 @@ extern "C" int paris_hip_convert_projection_f16(paris_hip_ctx* ctx, const float*
     const dim3 grid((dim_x + 255u) / 256u, dim_y < 65535u ? dim_y : 65535u);
     hipLaunchKernelGGL(to_half_kernel, grid, dim3(256), 0, ctx->stream, d_src, static_cast<uint32_t>(src_pitch / sizeof(float)),
                        reinterpret_cast<_Float16*>(d_dst), static_cast<uint32_t>(dst_pitch / sizeof(uint16_t)), dim_x, dim_y);
-    if(int rc = paris_hip_note_projection_use(ctx, d_src))
+    if(int rc = paris_hip_note_projection_use(ctx, d_src, src_pitch * dim_y))
         return rc;
     return paris_hip_finish(ctx);
 }
@@ -937,7 +937,7 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
             PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
         ++ctx->bp_launches;
         for(uint32_t i = 0; i < n && !ctx->upload_targets.empty(); ++i)
-            if(int rc = paris_hip_note_projection_use(ctx, p0 + static_cast<size_t>(i) * p_stride_bytes))
+            if(int rc = paris_hip_note_projection_use(ctx, p0 + static_cast<size_t>(i) * p_stride_bytes, p_pitch * p_dim_y))
                 return rc;
     }
     return paris_hip_finish(ctx);

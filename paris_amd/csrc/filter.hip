@@ -555,7 +555,7 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
         if(int rc = paris_hip_fused_filter_launch(ctx, d_p, pitch_f, dim_x, dim_y, fuse ? w.row_first : 0u, fuse, w.h_min, w.v_min, w.d_sd,
                                                   w.l_px_row, w.l_px_col, info->d_kp, plan, filter_size, nullptr, 0u))
             return rc;
-        if(int rc = paris_hip_note_projection_use(ctx, d_p))
+        if(int rc = paris_hip_note_projection_use(ctx, d_p, pitch * dim_y))
             return rc;
         return paris_hip_finish(ctx);
     }
@@ -574,13 +574,13 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
         }
         if(rc != PARIS_HIP_SUCCESS)
             return rc;
-        if(int rc2 = paris_hip_note_projection_use(ctx, d_p))
+        if(int rc2 = paris_hip_note_projection_use(ctx, d_p, pitch * dim_y))
             return rc2;
         return paris_hip_finish(ctx);
     }
     hipLaunchKernelGGL(apply_filter_kernel, dim3((dim_y + 1u) / 2u), dim3(threads_for(filter_size)),
                        filter_size * sizeof(float2), ctx->stream, d_p, pitch_f, dim_x, dim_y, d_k, plan->d_twiddle, log2n);
-    if(int rc = paris_hip_note_projection_use(ctx, d_p))
+    if(int rc = paris_hip_note_projection_use(ctx, d_p, pitch * dim_y))
         return rc;
     return paris_hip_finish(ctx);
 }
@@ -615,7 +615,7 @@ extern "C" int paris_hip_weight_filter_rows(paris_hip_ctx* ctx, float* d_p, size
                                               d_sd, l_px_row, l_px_col, info->d_kp, plan, filter_size, half_rows,
                                               static_cast<uint32_t>(half_pitch / sizeof(uint16_t))))
         return rc;
-    if(int rc = paris_hip_note_projection_use(ctx, d_p))
+    if(int rc = paris_hip_note_projection_use(ctx, rows, pitch * row_count))
         return rc;
     return paris_hip_finish(ctx);
 }

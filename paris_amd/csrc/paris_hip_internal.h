@@ -140,19 +140,25 @@ inline int paris_hip_finish(paris_hip_ctx* ctx)
     return PARIS_HIP_SUCCESS;
 }
 
-// called by every stage entry point after it has enqueued work that reads or writes the projection buffer d_p
-inline int paris_hip_note_projection_use(paris_hip_ctx* ctx, const void* d_p)
+// called by every stage entry point after it has enqueued work that reads or writes `bytes` bytes of projection memory
+// starting at d_p (a whole frame, or the rows of a band): every registered upload destination that overlaps the range gets
+// its last-use event re-recorded. Uploads and stage calls may address different row ranges of one frame buffer.
+inline int paris_hip_note_projection_use(paris_hip_ctx* ctx, const void* d_p, size_t bytes)
 {
     if(ctx->upload_targets.empty())
         return PARIS_HIP_SUCCESS;
-    auto it = ctx->upload_targets.upper_bound(d_p); // the registered buffer that contains d_p, if any
-    if(it == ctx->upload_targets.begin())
-        return PARIS_HIP_SUCCESS;
-    --it;
-    if(static_cast<const char*>(d_p) >= static_cast<const char*>(it->first) + it->second.bytes)
-        return PARIS_HIP_SUCCESS;
-    PARIS_HIP_TRY(hipEventRecord(it->second.last_use, ctx->stream));
-    it->second.used = true;
+    const char* lo = static_cast<const char*>(d_p);
+    const char* hi = lo + (bytes ? bytes : 1u);
+    auto it = ctx->upload_targets.upper_bound(d_p); // first target that starts behind lo; the one before may still reach into the range
+    if(it != ctx->upload_targets.begin())
+        --it;
+    for(; it != ctx->upload_targets.end() && static_cast<const char*>(it->first) < hi; ++it)
+    {
+        if(static_cast<const char*>(it->first) + it->second.bytes <= lo)
+            continue;
+        PARIS_HIP_TRY(hipEventRecord(it->second.last_use, ctx->stream));
+        it->second.used = true;
+    }
     return PARIS_HIP_SUCCESS;
 }
 

@@ -36,7 +36,7 @@ static int weight_rows_now(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_
     const dim3 grid((dim_x + 255u) / 256u, row_count < 65535u ? row_count : 65535u);
     hipLaunchKernelGGL(weight_kernel, grid, dim3(256), 0, ctx->stream, d_p, static_cast<uint32_t>(pitch / sizeof(float)),
                        dim_x, row_first, row_first + row_count, h_min, v_min, d_sd, l_px_row, l_px_col);
-    return paris_hip_note_projection_use(ctx, d_p);
+    return paris_hip_note_projection_use(ctx, reinterpret_cast<const char*>(d_p) + static_cast<size_t>(row_first) * pitch, pitch * row_count);
 }
 
 int paris_hip_flush_pending_weight(paris_hip_ctx* ctx)

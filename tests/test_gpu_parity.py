@@ -791,6 +791,52 @@ def test_upload_stream_orders_compute_behind_transfers(oracle, kat_golden):
     assert_bit_equal(got, kat_golden["volume"])
 
 
+@pytest.mark.parametrize("band", [False, True])
+def test_upload_into_a_busy_slot_waits_for_its_readers(oracle, band):
+    """paris_hip_upload_projection runs on the upload stream; re-uploading into a device slot whose
+    backprojections are still queued on the compute stream would overwrite pixels they have yet to read. The library orders
+    the upload behind the LAST call that touched that buffer (and nothing else). 1024 x 1024 frames into a 1024 x 1024 x 192
+    slab, four backprojections (~0.6 ms of queued kernels) read the slot, then a different frame is uploaded into it with NO
+    fence or sync in between and backprojected into a second volume: both volumes must equal the runs with a synchronize before
+    the re-upload. band=True: the upload and the stage calls address only a band of rows (an interior pointer of the slot)."""
+    import torch
+    n = 1024
+    det = B.DetectorGeometry(n, n, 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 1.0)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
+    z0, dz = 416, 192
+    first, count = (B.slab_row_band(det, vg, n, n, dz, z0) if band else (0, n))
+    frames = [torch.from_numpy(oracle.lcg_projection(n, n, 40 + i) - np.float32(0.5)).pin_memory() for i in range(2)]
+
+    def run(sync_before_reupload):
+        with B.Backend(0, synchronous=False) as abe:
+            L = abe._L
+            slot = abe.make_projection_device(n, n)
+            va, vb = abe.make_volume_device(n, n, dz), abe.make_volume_device(n, n, dz)
+
+            def up(t):
+                rows = t.numpy()[first:first + count]
+                B._lib.check(L.paris_hip_upload_projection(abe._ctx, slot.ptr + first * slot.pitch, slot.pitch, rows.ctypes.data, n * 4, n,
+                                                           count), "upload")
+            up(frames[0])
+            for i in range(4):
+                slot.idx = 7 * i
+                B.backproject(abe, slot, va, z0, det, vg, False, False, None)   # four queued readers of the slot
+            if sync_before_reupload:
+                abe.synchronize()
+            up(frames[1])                                                        # same slot, no fence
+            slot.idx = 3
+            B.backproject(abe, slot, vb, z0, det, vg, False, False, None)
+            abe.synchronize()
+            return volume_to_host(abe, va), volume_to_host(abe, vb)
+
+    want_a, want_b = run(True)
+    got_a, got_b = run(False)
+    assert_bit_equal(got_a, want_a)
+    assert_bit_equal(got_b, want_b)
+    assert np.abs(want_a).max() > 0 and not np.array_equal(want_a, want_b)
+
+
 @pytest.mark.parametrize("depth,launches", [(2, 4), (5, 2), (16, 1), (64, 1)])
 def test_deferred_backprojection_is_bit_identical(oracle, kat_golden, depth, launches):
     """paris_hip_set_backproject_deferral: the per-projection calls of the plugin boundary are snapshotted and added by
