@@ -257,10 +257,10 @@ namespace
                 const float4 y4 = *reinterpret_cast<const float4*>(c_ymax + c);
                 const int4 o4 = *reinterpret_cast<const int4*>(c_xoff + c);
                 const int4 i4 = *reinterpret_cast<const int4*>(c_x1i + c);
-                acc[r].x += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.x, u4.x, a4.x, b4.x, y4.x, o4.x, i4.x, FAST});
-                acc[r].y += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.y, u4.y, a4.y, b4.y, y4.y, o4.y, i4.y, FAST});
-                acc[r].z += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.z, u4.z, a4.z, b4.z, y4.z, o4.z, i4.z, FAST});
-                acc[r].w += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.w, u4.w, a4.w, b4.w, y4.w, o4.w, i4.w, FAST});
+                acc[r].x += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.x, u4.x, a4.x, b4.x, y4.x, o4.x, i4.x, FAST, false});
+                acc[r].y += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.y, u4.y, a4.y, b4.y, y4.y, o4.y, i4.y, FAST, false});
+                acc[r].z += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.z, u4.z, a4.z, b4.z, y4.z, o4.z, i4.z, FAST, false});
+                acc[r].w += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.w, u4.w, a4.w, b4.w, y4.w, o4.w, i4.w, FAST, false});
             }
         };
         if(all_fast)

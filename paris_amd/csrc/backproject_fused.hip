@@ -75,16 +75,18 @@ namespace
             if(active)
             {
                 Column col[VX];
-                bool all_fast = true;
+                bool all_fast = true, all_inside = true;
 #pragma unroll
                 for(int j = 0; j < VX; ++j)
                 {
                     col[j] = make_column<FD>(g, box, g.k_off + k + j, g.l_off + l, z_first, z_last);
                     all_fast = all_fast && col[j].fast;
+                    all_inside = all_inside && col[j].inside;
                 }
-                auto add_projection = [&](auto fast_tag, auto full_tag) {
+                auto add_projection = [&](auto fast_tag, auto full_tag, auto inside_tag) {
                     constexpr bool FAST = decltype(fast_tag)::value;
                     constexpr bool FULL = decltype(full_tag)::value; // whole tile: no per-slice test, one straight block
+                    constexpr bool INSIDE = decltype(inside_tag)::value; // every tap valid: no validity test, clamp or select
 #pragma unroll
                     for(int z = 0; z < TZ; ++z)
                     {
@@ -93,16 +95,21 @@ namespace
                             const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + z) * g.l_vx_z; // :118
 #pragma unroll
                             for(int j = 0; j < VX; ++j)
-                                elem<VX>(acc[z], j) += voxel_contribution<FD, FAST>(g, box, lds, z_m, col[j]);
+                                elem<VX>(acc[z], j) += voxel_contribution<FD, FAST, INSIDE>(g, box, lds, z_m, col[j]);
                         }
                     }
                 };
-                if(all_fast && mcount == TZ)
-                    add_projection(std::true_type{}, std::true_type{});
+                // Wave-uniform choice of the all-valid path (a wave with one boundary lane takes the fast path for all its lanes:
+                // a per-lane branch would run both bodies). Interior tiles -- most of the field of view -- take it.
+                const bool wave_inside = mcount == TZ && __all(all_inside ? 1 : 0) != 0;
+                if(wave_inside)
+                    add_projection(std::true_type{}, std::true_type{}, std::true_type{});
+                else if(all_fast && mcount == TZ)
+                    add_projection(std::true_type{}, std::true_type{}, std::false_type{});
                 else if(all_fast)
-                    add_projection(std::true_type{}, std::false_type{});
+                    add_projection(std::true_type{}, std::false_type{}, std::false_type{});
                 else
-                    add_projection(std::false_type{}, std::false_type{});
+                    add_projection(std::false_type{}, std::false_type{}, std::false_type{});
             }
         }
 #pragma unroll

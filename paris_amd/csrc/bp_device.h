@@ -405,6 +405,7 @@ namespace
         int xoff;       // LDS column of the left tap, or -1 when it is not inside the staged box
         int x1i;        // detector column of the left tap (global-memory path)
         bool fast;      // every valid tap of this column, over the tile's whole z range, lies inside the staged box
+        bool inside;    // stronger: EVERY tap of this column over the tile's z range is valid and inside the staged box
     };
 
     // z_first / z_last: centred z of the tile's first and last slice. The per-slice coordinate v is a monotone
@@ -440,16 +441,24 @@ namespace
         const bool rows_inside = (r_lo > r_hi) || (r_lo >= b.by0 && r_hi <= b.by0 + b.bhs - 2);
         const bool finite_factor = (c.factor - c.factor) == 0.f; // with a finite factor v is never NaN (it may overflow to inf)
         col.fast = !x_valid || (ordered && finite_factor && col.xoff >= 0 && rows_inside);
+        // All taps valid: the unclamped rows of both end slices lie in [by0, by0 + bhs - 2] (the box is clipped to the detector, so
+        // a row pair inside it is a valid pair). floor(v) >= by0 <=> v >= by0 and floor(v) <= by0 + bhs - 2 <=> v < by0 + bhs - 1
+        // for the integers by0, bhs; a NaN fails both comparisons. By the monotonicity argument above every slice in between is
+        // inside too: such a column needs neither the per-voxel validity test nor the row clamp nor the final select.
+        col.inside = x_valid && finite_factor && col.xoff >= 0 && b.bhs >= 2
+                     && fminf(va, vb) >= static_cast<float>(b.by0) && fmaxf(va, vb) < static_cast<float>(b.by0 + b.bhs - 1);
         return col;
     }
 
     // one voxel-update: src/openmp/backprojection.cpp:130-140 for slice coordinate z_m of column col
     // FAST: the column was proven to stay inside the staged box (Column::fast), so the global-memory path and its
     // branch are compiled out and the body is straight-line code the scheduler can overlap across voxels.
-    template <bool FD, bool FAST>
+    // ALLVALID (implies FAST): the column was proven to have every tap valid and inside the box (Column::inside)
+    template <bool FD, bool FAST, bool ALLVALID = false>
     __device__ __forceinline__ float voxel_contribution(const BpParams& g, const Box& b, const float* lds_box, float z_m,
                                                         const Column& col)
     {
+        static_assert(!ALLVALID || FAST, "ALLVALID is a refinement of FAST");
         const float v = v_coordinate<FD>(g, z_m, col.factor);
         float y1 = 0.f, y2 = 0.f;
         int y1i;
@@ -467,8 +476,11 @@ namespace
         }
         const int rrel = y1i - b.by0;
         const int bhs_m2 = b.bhs - 2;
-        bool valid;
-        if(FAST)
+        bool valid = true;
+        if(ALLVALID)
+        {
+        }
+        else if(FAST)
         {
             // For a `fast` column "valid" (:65-68) is the same as "row and row + 1 inside the staged box": valid taps are
             // inside by construction of `fast`, and the box is clipped to the detector, so a row pair inside it is a
@@ -481,8 +493,9 @@ namespace
         else
             valid = (y1 >= 0.f) && (y2 < col.ymax); // :67-68 (+ x validity)
         // clamp of the row to the staged box: one median instruction (the compiler's min/max pair cannot know 0 <= hi)
-        int rc;
-        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(rc) : "v"(rrel), "v"(max(bhs_m2, 0)));
+        int rc = rrel; // ALLVALID: 0 <= rrel <= bhs - 2 by construction
+        if(!ALLVALID)
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(rc) : "v"(rrel), "v"(max(bhs_m2, 0)));
         // LDS byte address of the upper left tap = row * stride4 + (box base + 4 * column): the second term is z-invariant
         // (hoisted with the column state), so a tap pair costs one 24-bit multiply-add (rc < 2^12, stride4 < 2^16;
         // v_mul_lo_u32 is quarter rate) and the row below one add. Integer addresses keep the compiler from adding the
@@ -522,7 +535,8 @@ namespace
         const float wy1 = (FAST && PARIS_BP_SINGLE_INSTRUCTION_FLOOR) ? __builtin_amdgcn_fractf(v) : v - y1;
         const float wy2 = FAST ? 1.f - wy1 : y2 - v;
         float det = wy2 * interp_y1 + wy1 * interp_y2;
-        det = valid ? det : 0.f;         // :71
+        if(!ALLVALID)
+            det = valid ? det : 0.f;     // :71
         return 0.5f * det * col.u * col.u; // :140
     }
 
