@@ -317,7 +317,12 @@ namespace
             const int end = min((bx1 + 4) & ~3, static_cast<int>(g.p_pitch));
             b.bx0 &= ~3;
             b.bw = end - b.bx0;
-            b.stride = b.bw + 4; // multiple of 4: 16-byte aligned rows for ds_write_b128, not a power of two
+            // multiple of 4 (16-byte aligned rows for ds_write_b128) and an ODD multiple: rows r, r + 1, ... r + 7 then start in
+            // eight different groups of four banks, so lanes of one wave that tap different detector rows (the wave spans several
+            // volume rows) do not pile onto the same banks as they do with a stride of 0, 8 or 16 mod 32
+            b.stride = b.bw + 4;
+            if(((b.stride >> 2) & 1) == 0)
+                b.stride += 4;
         }
         else
             b.stride = b.bw | 1;
