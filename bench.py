@@ -223,6 +223,7 @@ def main():
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--tz", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0, help="backprojection kernel variant (0: default; 5: two-pass, column constants precomputed per projection)")
     ap.add_argument("--order", type=int, default=-1, help="workgroup -> tile order of the backprojection kernel (-1: the library's default)")
     ap.add_argument("--fused-steps", type=int, default=8, help="extra steps with the fused multi-projection kernel, "
                     "reported as fused_extension next to the headline (0 disables); the steps are spread over the circle")
@@ -301,6 +302,8 @@ def main():
     be.set_backproject_tuning(args.vx, args.unroll, args.tz, args.lds_bytes)
     if args.order >= 0:
         be.set_backproject_order(args.order, -1)
+    if args.variant:
+        be.set_backproject_variant(args.variant)
     # paris::weight is held back and rides along in the load of the paris::filter call that follows: one launch for the pair
     be.set_stage_fusion(bool(args.stage_fusion))
 

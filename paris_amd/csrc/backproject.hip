@@ -53,7 +53,24 @@ namespace
     // Tile kernel (z-walk in time). 1-D grid over ntx * nty * ntz tiles of 64 x TY x g.tz voxels, TY = 4*VX.
     // Serves every alignment (VX = 1, 2, 4).
     // --------------------------------------------------------------------------------------------
-    template <int VX, int UNROLL, bool NT, bool FD>
+    // Two-pass variant, pass A: the z-invariant constants of every (x,y) column of the slab's plane for this projection,
+    // computed once instead of once per tile (src/openmp/backprojection.cpp:116-129,139): three planes factor / h / u.
+    template <bool FD>
+    __global__ void __launch_bounds__(256) bp_column_state_kernel(const BpParams g, float* __restrict__ st)
+    {
+        const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+        const uint32_t l = blockIdx.y;
+        if(k >= g.v_dim_x)
+            return;
+        const ColConst c = column_constants<FD>(g, g.k_off + k, g.l_off + l);
+        const size_t plane = static_cast<size_t>(g.v_dim_x) * g.v_dim_y;
+        const size_t at = static_cast<size_t>(l) * g.v_dim_x + k;
+        st[at] = c.factor;
+        st[plane + at] = c.h;
+        st[2u * plane + at] = c.u;
+    }
+
+    template <int VX, int UNROLL, bool NT, bool FD, bool PRE = false>
     __global__ void __launch_bounds__(256) bp_tile_kernel(const BpParams g)
     {
         extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -76,15 +93,27 @@ namespace
         const uint32_t l1 = min(l0 + TY - 1u, g.v_dim_y - 1u);
         const uint32_t m1 = min(m0 + g.tz - 1u, g.v_dim_z - 1u);
 
-        const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats);
-        stage_box(g, box, lds, wave, 4u, lane);
-
         // ---- per-lane columns --------------------------------------------------------------------
         const uint32_t xq = lane % XL;
         const uint32_t yy = lane / XL;
         const uint32_t k = k0 + xq * VX;
         const uint32_t l = l0 + wave * RW + yy;
         const bool active = k < g.v_dim_x && l < g.v_dim_y;
+
+        // two-pass variant: this lane's column constants were written by bp_column_state_kernel; requested before the box so
+        // that both travel together (VX == 4, dim_x % 4 == 0: one 16-byte load per plane)
+        float4 pre_f = make_float4(0.f, 0.f, 0.f, 0.f), pre_h = pre_f, pre_u = pre_f;
+        if(PRE && VX == 4)
+        {
+            const size_t plane = static_cast<size_t>(g.v_dim_x) * g.v_dim_y;
+            const size_t at = static_cast<size_t>(min(l, l1)) * g.v_dim_x + min(k, g.v_dim_x - 4u);
+            pre_f = *reinterpret_cast<const float4*>(g.colstate + at);
+            pre_h = *reinterpret_cast<const float4*>(g.colstate + plane + at);
+            pre_u = *reinterpret_cast<const float4*>(g.colstate + 2u * plane + at);
+        }
+
+        const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats);
+        stage_box(g, box, lds, wave, 4u, lane);
 
         const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
         const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
@@ -93,7 +122,16 @@ namespace
 #pragma unroll
         for(int j = 0; j < VX; ++j)
         {
-            col[j] = make_column<FD>(g, box, g.k_off + min(k + j, k1), g.l_off + min(l, l1), z_first, z_last);
+            if(PRE && VX == 4)
+            {
+                ColConst c;
+                c.factor = elem<4>(pre_f, j);
+                c.h = elem<4>(pre_h, j);
+                c.u = elem<4>(pre_u, j);
+                col[j] = make_column_from<FD>(g, box, c, z_first, z_last);
+            }
+            else
+                col[j] = make_column<FD>(g, box, g.k_off + min(k + j, k1), g.l_off + min(l, l1), z_first, z_last);
             all_fast = all_fast && col[j].fast;
         }
 
@@ -356,6 +394,19 @@ namespace
             launch_tile_unroll<VX, false, true>(g, unroll, stream);
         else
             launch_tile_unroll<VX, false, false>(g, unroll, stream);
+    }
+
+    // two-pass variant (variant 5): pass A writes the column constants of the whole plane, pass B is the tile kernel reading them
+    template <int UNROLL, bool FD>
+    void launch_tile_pre(BpParams& g, hipStream_t stream)
+    {
+        g.ntx = (g.v_dim_x + 63u) / 64u;
+        g.nty = (g.v_dim_y + 15u) / 16u;
+        g.ntz = (g.v_dim_z + g.tz - 1u) / g.tz;
+        g.zchunk = std::max(1u, 256u / std::max(1u, g.tz));
+        hipLaunchKernelGGL((bp_column_state_kernel<FD>), dim3((g.v_dim_x + 255u) / 256u, g.v_dim_y), dim3(256), 0, stream, g,
+                           const_cast<float*>(g.colstate));
+        hipLaunchKernelGGL((bp_tile_kernel<4, UNROLL, true, FD, true>), dim3(grid_blocks(g)), dim3(256), g.lds_floats * sizeof(float), stream, g);
     }
 
     // ---- slice kernel launchers ------------------------------------------------------------------------------
@@ -645,6 +696,26 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
             const uint32_t box_bytes = ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT;
             if(int rc = launch_slice_shape(g, nw, rpl, box_bytes, nt, fd, ctx->stream))
                 return rc;
+        }
+        else if(vx == 4 && ctx->bp_variant == 5 && v_dim_y <= 65535u)
+        {
+            const size_t need = 3u * static_cast<size_t>(v_dim_x) * v_dim_y;
+            if(ctx->colstate_floats < need)
+            {
+                if(ctx->colstate != nullptr)
+                {
+                    PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    PARIS_HIP_TRY(hipFree(ctx->colstate));
+                    ctx->colstate = nullptr;
+                }
+                PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->colstate), need * sizeof(float)));
+                ctx->colstate_floats = need;
+            }
+            g.colstate = ctx->colstate;
+            if(unroll == 1)
+                fd ? launch_tile_pre<1, true>(g, ctx->stream) : launch_tile_pre<1, false>(g, ctx->stream);
+            else
+                fd ? launch_tile_pre<2, true>(g, ctx->stream) : launch_tile_pre<2, false>(g, ctx->stream);
         }
         else if(vx == 4)
             launch_tile_flags<4>(g, unroll, nt, fd, ctx->stream);
@@ -961,7 +1032,7 @@ extern "C" int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant
 {
     if(int rc = paris_hip_flush_deferred(ctx))
         return rc;
-    if(ctx == nullptr || variant < 0 || variant > 4)
+    if(ctx == nullptr || variant < 0 || variant > 5)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_variant = variant;
     return PARIS_HIP_SUCCESS;

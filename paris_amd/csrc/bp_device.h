@@ -43,6 +43,7 @@ namespace
         uint32_t ntx, nty, ntz; // tiles per axis
         uint32_t order;         // workgroup -> tile mapping, see tile_of_block
         uint32_t zchunk;        // order 12: z tiles per chunk
+        const float* colstate;  // two-pass variant: factor, h, u planes of v_dim_x * v_dim_y floats each (NULL: computed in the kernel)
         uint32_t store_sc1;     // nontemporal stores also carry sc1 (write-through)
         uint32_t stage_vec4;    // detector rows may be staged 4 pixels at a time (base and pitch aligned)
     };
@@ -419,10 +420,20 @@ namespace
     // lie between the rows touched at its two end slices: `fast` is decided from those two evaluations alone, with
     // the very expression the slice loop uses, and needs no error bound.
     template <bool FD>
+    __device__ __forceinline__ Column make_column_from(const BpParams& g, const Box& b, const ColConst& c, float z_first, float z_last);
+
+    template <bool FD>
     __device__ __forceinline__ Column make_column(const BpParams& g, const Box& b, uint32_t K, uint32_t L, float z_first,
                                                   float z_last)
     {
-        const ColConst c = column_constants<FD>(g, K, L);
+        return make_column_from<FD>(g, b, column_constants<FD>(g, K, L), z_first, z_last);
+    }
+
+    // the same from column constants computed elsewhere (two-pass variant: bp_column_state_kernel wrote them for every column
+    // of the plane, with column_constants<FD> itself)
+    template <bool FD>
+    __device__ __forceinline__ Column make_column_from(const BpParams& g, const Box& b, const ColConst& c, float z_first, float z_last)
+    {
         const float x1 = floorf(c.h); // :55-58
         const float x2 = x1 + 1.f;
         const bool x_valid = (x1 >= 0.f) && (x2 < g.p_dim_x_f); // :65-66

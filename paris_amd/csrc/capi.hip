@@ -182,6 +182,8 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
             (void)hipFree(kv.second.d_kp);
     if(ctx->d_sincos != nullptr)
         (void)hipFree(ctx->d_sincos);
+    if(ctx->colstate != nullptr)
+        (void)hipFree(ctx->colstate);
     for(auto& kv : ctx->proj_pool)
     {
         (void)hipEventDestroy(kv.second.released);

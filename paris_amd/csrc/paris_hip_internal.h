@@ -126,6 +126,9 @@ struct paris_hip_ctx
     paris_region_of_interest key_roi{};
     float key_delta_s = 0.f, key_delta_t = 0.f;
     std::vector<float> defer_sin, defer_cos;
+    // two-pass backprojection (variant 5): factor / h / u planes of the slab's (x, y) plane, rewritten per projection
+    float* colstate = nullptr;
+    size_t colstate_floats = 0;
     // device copies of the per-projection sin/cos for the batched launch
     float* d_sincos = nullptr;
     uint32_t d_sincos_cap = 0;

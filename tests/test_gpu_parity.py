@@ -470,6 +470,31 @@ def test_backproject_every_tile_order_bit_exact(be, oracle, order, tz, dims):
         be.set_backproject_order()
 
 
+@pytest.mark.parametrize("tz,order,unroll", [(4, 12, 1), (8, 12, 2), (16, 5, 2), (2, 8, 1)])
+def test_backproject_two_pass_variant_bit_exact(be, oracle, tz, order, unroll):
+    """Variant 5: the column constants of the whole (x, y) plane are computed once per projection by a first kernel and read by
+    the tile kernel (shallow tiles then pay no column setup). Same arithmetic, so the oracle's bits; ROI + slab offset."""
+    g = (96, 80, 0.2, 0.25, -2.5, 1.25, 150, 250, 40.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(260, 170, 120, nat.l_vx_x * 0.4, nat.l_vx_x * 0.45, nat.l_vx_x * 0.3)
+    ovg = oracle.VolumeGeometry(260, 170, 120, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    roi, oroi = B.RegionOfInterest(20, 220, 10, 160, 5, 100), oracle.RegionOfInterest(20, 220, 10, 160, 5, 100)
+    dims = (60, 150, 200)
+    projs = [oracle.lcg_projection(96, 80, i) - np.float32(0.5) for i in range(3)]
+    want = oracle_backproject_all(oracle, projs, odet, ovg, dims, v_offset=17, roi=oroi)
+    be.set_backproject_variant(5)
+    be.set_backproject_tuning(unroll=unroll, tz=tz)
+    be.set_backproject_order(order, -1)
+    try:
+        got = hip_backproject_all(be, projs, det, vg, dims, v_offset=17, roi=roi)
+    finally:
+        be.set_backproject_variant(0)
+        be.set_backproject_tuning()
+        be.set_backproject_order()
+    assert_bit_equal(got, want)
+
+
 @pytest.mark.parametrize("fast", [False, True])
 @pytest.mark.parametrize("vec", [False, True])
 def test_backproject_fast_division_and_staging_switches(be, oracle, kat_golden, fast, vec):
