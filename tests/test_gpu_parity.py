@@ -304,6 +304,49 @@ def test_fused_weight_filter_equals_the_two_stages(be_async, oracle, n_row, n_co
     be.free(k)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PARIS_FILTER_FUZZ_SEEDS", "10"))))
+def test_fused_weight_filter_random_sizes(be_async, oracle, seed):
+    """Seeded random detector sizes for the one-launch weight + filter (filter lengths 1024 ... 8192, widths on both sides of the
+    power-of-two boundaries, odd row counts, random pitches / offsets / distances, a random band of whole row pairs): the held-back
+    weight() + filter() pair through the stage wrappers equals the two launches bit for bit and the oracle within the filter
+    tolerance; rows outside the band stay raw."""
+    be = be_async
+    rng = np.random.default_rng(7000 + seed)
+    n_row = int(rng.choice([rng.integers(257, 513), rng.integers(500, 1030), rng.integers(1020, 2060), rng.integers(2040, 4097),
+                            512, 513, 1024, 1025, 2048, 2049]))
+    n_col = int(rng.integers(1, 40))
+    g = (n_row, n_col, float(rng.choice([0.1, 0.2, 0.127, 0.4])), float(rng.choice([0.1, 0.2, 0.25])), float(rng.uniform(-5, 5)),
+         float(rng.uniform(-5, 5)), float(rng.uniform(50, 600)), float(rng.uniform(50, 600)), 1.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    fs = oracle.filter_size(n_row)
+    assert fs >= 1024
+    p = (oracle.lcg_projection(n_row, n_col, seed) - np.float32(0.4)) * np.float32(rng.uniform(0.5, 200))
+    first = 2 * int(rng.integers(0, max(1, n_col // 2)))
+    count = min(n_col - first, 2 * int(rng.integers(1, 12)))
+
+    be.set_stage_fusion(False)
+    d_a = to_device(be, p)
+    B.weight_rows(be, d_a, det, first, count)
+    B.filter_rows(be, d_a, det, first, count)
+    two = to_host(be, d_a)
+    be.set_stage_fusion(True)
+    try:
+        d_b = to_device(be, p)
+        B.weight_rows(be, d_b, det, first, count)   # held back
+        B.filter_rows(be, d_b, det, first, count)   # weights in its load
+        one = to_host(be, d_b)
+    finally:
+        be.set_stage_fusion(False)
+    assert np.array_equal(one.view(np.uint32), two.view(np.uint32))
+    assert np.array_equal(one[:first], p[:first]) and np.array_equal(one[first + count:], p[first + count:])
+    want_w = oracle.weight(p.copy(), odet)
+    want = oracle.apply_filter(want_w.copy(), oracle.make_filter(fs, det.l_px_row), fs)[first:first + count]
+    scale = max(np.abs(want).max(), 1e-30)
+    assert np.max(np.abs(one[first:first + count] - want)) <= FILTER_TOL * scale
+    be.free(d_a)
+    be.free(d_b)
+
+
 def test_fused_filter_needs_a_library_filter(be_async, oracle):
     """the one-launch entry point refuses a K it has no permuted copy of, and lengths below 1024 (the caller runs two stages)"""
     be = be_async
@@ -1257,13 +1300,24 @@ def test_backproject_random_geometries_bit_exact(be, oracle, seed):
         s, c, ds, dt = oracle.backproject_constants(odet, i, True, angles[i])
         oracle.backproject(want, p, v_offset, odet, ovg, s, c, ds, dt, oroi)
 
-    d_v = be.make_volume_device(dims[2], dims[1], dims[0])
-    for i, p in enumerate(projs):
-        d_p = to_device(be, p, idx=i, phi=angles[i])
-        B.backproject(be, d_p, d_v, v_offset, det, vg, True, use_roi, roi)
-        be.free(d_p)
-    assert_bit_equal(volume_to_host(be, d_v), want)
-    be.free(d_v)
+    # every other seed forces one of the workgroup -> tile orders and a tile depth (the defaults pick by volume shape, and these
+    # volumes are small: without this the band orders 8 / 9 / 12 and shallow tiles would only be fuzzed at full size)
+    forced = seed % 2 == 1
+    if forced:
+        be.set_backproject_order(int(rng.choice([0, 1, 5, 8, 9, 12])), -1)
+        be.set_backproject_tuning(tz=int(rng.choice([2, 5, 8, 16])))
+    try:
+        d_v = be.make_volume_device(dims[2], dims[1], dims[0])
+        for i, p in enumerate(projs):
+            d_p = to_device(be, p, idx=i, phi=angles[i])
+            B.backproject(be, d_p, d_v, v_offset, det, vg, True, use_roi, roi)
+            be.free(d_p)
+        assert_bit_equal(volume_to_host(be, d_v), want)
+        be.free(d_v)
+    finally:
+        if forced:
+            be.set_backproject_order()
+            be.set_backproject_tuning()
 
     # f4: rows outside paris_hip_slab_row_band never reach the slab -- poison them with NaN. A thin sub-slab, so that
     # the band is a real subset of the detector in most cases.

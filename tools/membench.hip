@@ -119,6 +119,36 @@ __global__ void __launch_bounds__(256) tile(float* vol, uint32_t dx, uint32_t dy
     }
 }
 
+// tall tiles: 64 x (16 RG) columns, every lane owns RG row groups (16 rows apart) of each slice; IF slices in flight
+template <int RG, int IF, int POL>
+__global__ void __launch_bounds__(256) tile_tall(float* vol, uint32_t dx, uint32_t dy, uint32_t dz, uint32_t tz, uint32_t order)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t bx, by, bz;
+    tile_of(blockIdx.x, order, dx / 64u, dy / (16u * RG), dz / tz, bx, by, bz);
+    const uint32_t k = bx * 64u + (lane & 15u) * 4u;
+    const uint32_t l = by * 16u * RG + wave * 4u + (lane >> 4);
+    const size_t slice = (size_t)dx * dy;
+    float* vp = vol + ((size_t)bz * tz * dy + l) * dx + k;
+    for(uint32_t m = 0; m + IF <= tz; m += IF, vp += IF * slice)
+    {
+        v4f q[IF][RG];
+#pragma unroll
+        for(int i = 0; i < IF; ++i)
+#pragma unroll
+            for(int r = 0; r < RG; ++r)
+                q[i][r] = ld<POL>(vp + (size_t)i * slice + (size_t)r * 16u * dx);
+#pragma unroll
+        for(int i = 0; i < IF; ++i)
+#pragma unroll
+            for(int r = 0; r < RG; ++r)
+            {
+                q[i][r] += 1.f;
+                st<POL>(vp + (size_t)i * slice + (size_t)r * 16u * dx, q[i][r]);
+            }
+    }
+}
+
 // NW waves, one slice each, of a 64 x 16 tile (4 row groups of 4 rows per wave)
 template <int NW, int POL>
 __global__ void __launch_bounds__(NW * 64) zwave(float* vol, uint32_t dx, uint32_t dy, uint32_t dz, uint32_t order)
@@ -231,6 +261,17 @@ int main(int argc, char** argv)
         add("tile 64x16x16 order 5 if2 plain", [=] { tile<16, 2, PLAIN><<<g, 256>>>(a, dx, dy, dz, 16, 5); });
         add("tile 64x16x16 order 5 if2 nt", [=] { tile<16, 2, NT><<<g, 256>>>(a, dx, dy, dz, 16, 5); });
     }
+    for(uint32_t order : {5u, 8u})
+        for(uint32_t tz : {4u, 8u, 16u})
+        {
+            char nm[128];
+            snprintf(nm, sizeof nm, "tall tile 64x32x%u order %u if2 ntsc1", tz, order);
+            add(nm, [=] { tile_tall<2, 2, NTSC1><<<(dx / 64) * (dy / 32) * (dz / tz), 256>>>(a, dx, dy, dz, tz, order); });
+            snprintf(nm, sizeof nm, "tall tile 64x32x%u order %u if1 ntsc1", tz, order);
+            add(nm, [=] { tile_tall<2, 1, NTSC1><<<(dx / 64) * (dy / 32) * (dz / tz), 256>>>(a, dx, dy, dz, tz, order); });
+            snprintf(nm, sizeof nm, "tall tile 64x64x%u order %u if1 ntsc1", tz, order);
+            add(nm, [=] { tile_tall<4, 1, NTSC1><<<(dx / 64) * (dy / 64) * (dz / tz), 256>>>(a, dx, dy, dz, tz, order); });
+        }
     add("zwave 8 waves order 5 ntsc1", [=] { zwave<8, NTSC1><<<(dx / 64) * (dy / 16) * (dz / 8), 512>>>(a, dx, dy, dz, 5); });
     add("zwave 16 waves order 5 ntsc1", [=] { zwave<16, NTSC1><<<(dx / 64) * (dy / 16) * (dz / 16), 1024>>>(a, dx, dy, dz, 5); });
 
