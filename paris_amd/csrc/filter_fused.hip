@@ -23,6 +23,7 @@
 //   * optionally the last pass stores IEEE half pixels into a second buffer (BASELINE config 5) instead of fp32 in place.
 #include "paris_hip_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -32,6 +33,7 @@ namespace
     struct WeightParams
     {
         float h_min, v_min, d_sd, l_px_row, l_px_col;
+        uint32_t lean; // every radicand and quotient of this projection is far from the fp32 range limits (decided on the host)
     };
 
     __device__ __forceinline__ float column_term(const WeightParams& w, uint32_t s) // dd + hh of detector column s
@@ -52,11 +54,37 @@ namespace
         return v_t * v_t;
     }
 
+    // Correctly rounded sqrt and division as hipcc expands them (v_sqrt_f32 + the +-1 ulp residual test; v_rcp_f32 + one Newton
+    // step + two quotient corrections), minus the parts that only matter at the edges of the fp32 range: the 2^32 pre-scaling
+    // of radicands below 2^-96, the v_div_scale / v_div_fmas rescaling of extreme operands and the special-value fix-ups. For
+    // operands in the safe range those parts are the identity, so the results have the same bits (tests: fused == weight_kernel
+    // bit for bit over the seeded size / geometry fuzz); the host enables this only when d_sd^2 and the largest radicand of the
+    // projection lie in [2^-60, 2^60].
+    __device__ __forceinline__ float sqrt_rn_safe_range(float x)
+    {
+        float s = __builtin_amdgcn_sqrtf(x);
+        const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
+        const float r_lo = __builtin_fmaf(-lo, s, x), r_hi = __builtin_fmaf(-hi, s, x);
+        s = r_lo <= 0.f ? lo : s;
+        s = r_hi > 0.f ? hi : s;
+        return s;
+    }
+
+    __device__ __forceinline__ float div_rn_safe_range(float n, float d)
+    {
+        float r = __builtin_amdgcn_rcpf(d);
+        r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
+        float q = n * r;
+        q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+        return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    }
+
     __device__ __forceinline__ float weighted(const WeightParams& w, float px, float dd_hh, float vv)
     {
 #pragma clang fp contract(off)
-        const float w_st = w.d_sd / sqrtf(dd_hh + vv); // :52 (dd + hh + v_t * v_t, left to right)
-        return px * w_st;                               // :54
+        const float q = dd_hh + vv; // :52 (dd + hh + v_t * v_t, left to right)
+        const float w_st = w.lean ? div_rn_safe_range(w.d_sd, sqrt_rn_safe_range(q)) : w.d_sd / sqrtf(q);
+        return px * w_st;           // :54
     }
 
     // ---- butterflies with compile-time twiddles ---------------------------------------------------------------------------
@@ -194,7 +222,7 @@ namespace
     // HALF: dim_x <= N/2 (always true for the reference's filter length 2 * 2^ceil(log2 n_row)); WEIGHT: apply the cosine
     // weight in the load; F16OUT: store halves into half_out instead of fp32 in place
     template <int LOG2N, bool HALF, bool WEIGHT, bool F16OUT>
-    __global__ void __launch_bounds__((1 << LOG2N) / 16) filter_rows_kernel(const FusedFilterArgs a)
+    __global__ void __launch_bounds__((1 << LOG2N) / 16, 4) filter_rows_kernel(const FusedFilterArgs a) // 4 waves per SIMD: at most 128 VGPRs
     {
         constexpr uint32_t N = 1u << LOG2N;
         constexpr int NPASS = (LOG2N + 3) / 4;
@@ -541,7 +569,19 @@ int paris_hip_fused_filter_launch(paris_hip_ctx* ctx, float* d_rows, uint32_t pi
     a.dim_x = dim_x;
     a.n_rows = n_rows;
     a.row_first = row_first;
-    a.w = WeightParams{h_min, v_min, d_sd, l_px_row, l_px_col};
+    a.w = WeightParams{h_min, v_min, d_sd, l_px_row, l_px_col, 0u};
+    if(weight)
+    {
+        // the largest radicand d_sd^2 + h^2 + v^2 over the detector, in double: the lean sqrt / divide need it (and d_sd^2, the
+        // smallest) well inside the fp32 range
+        const double h0 = 0.5 * l_px_row + h_min, h1 = 0.5 * l_px_row + (static_cast<double>(dim_x) - 1.0) * l_px_row + h_min;
+        const double rows_all = static_cast<double>(row_first) + n_rows;
+        const double v0 = 0.5 * l_px_col + v_min, v1 = 0.5 * l_px_col + (rows_all - 1.0) * l_px_col + v_min;
+        const double dd = static_cast<double>(d_sd) * d_sd;
+        const double q_max = dd + std::max(h0 * h0, h1 * h1) + std::max(v0 * v0, v1 * v1);
+        const double lo = std::ldexp(1.0, -60), hi = std::ldexp(1.0, 60);
+        a.w.lean = (dd >= lo && q_max <= hi && std::isfinite(q_max) && d_sd > 0.f) ? 1u : 0u;
+    }
     a.kp = d_kp;
     a.tab_first = plan->d_tab_first;
     for(int k = 0; k < 3; ++k)
