@@ -483,8 +483,7 @@ def main():
 
         # ---- the same per-projection calls as the headline, with the library's deferral switched on: every
         # paris_hip_backproject call snapshots its projection, `batch` of them are added by one fused launch
-        # (fp32 calls only; the half-precision entry point is not deferred)
-        be.set_backproject_deferral(1 if f16 else fb)
+        be.set_backproject_deferral(fb)
         step(n_proj - fb, fb)
         be.flush()
         torch.cuda.synchronize()
@@ -595,7 +594,7 @@ def main():
         if fused is not None:
             per_launch = voxels_rank * fb
             out["fused_extension"] = fused_report(fused, fb, f16, voxels_rank, voxels_all, n_row, n_col, per_launch)
-            if not f16:
+            if fused.get("deferred_seconds"):
                 out["deferred_boundary"] = {
                     "what": "the headline's step unchanged -- one paris_hip_backproject call per projection -- with "
                             "paris_hip_set_backproject_deferral(%d): the library snapshots each call's projection and adds %d of "

@@ -255,15 +255,17 @@ int paris_hip_backproject_batch_f16(paris_hip_ctx* ctx, const uint16_t* d_p, siz
                                     int enable_roi, const paris_region_of_interest* roi, const float* sin_phi,
                                     const float* cos_phi, float delta_s, float delta_t);
 
-/* Extension: deferred backprojection. With depth n > 1 (n <= 64), paris_hip_backproject copies its projection into a ring
+/* Extension: deferred backprojection. With depth n > 1 (n <= 64), paris_hip_backproject (and paris_hip_backproject_f16:
+ * half-precision calls form groups of their own) copies its projection into a ring
  * owned by the ctx (stream-ordered device-to-device copy: the caller may reuse its buffer as after any asynchronous
  * call) and returns; the pending projections are added by ONE fused launch, in call order and bit-identical to n
  * single launches, when n are pending, when a call with another volume, slab, geometry or ROI arrives, and before
  * every entry point that observes or changes a volume, completes work or changes how backprojection runs
- * (paris_hip_ctx_synchronize, _fence_record, _memcpy_volume_*, _memset_volume, _free, _backproject_f16, _backproject_batch,
- * the timing and tuning calls, paris_hip_flush). The volume is then read and written once per n projections instead of
+ * (paris_hip_ctx_synchronize, _fence_record, _memcpy_volume_*, _memset_volume, _free, _backproject_batch, a call of the
+ * other precision, the timing and tuning calls, paris_hip_flush). The volume is then read and written once per n projections instead of
  * once per projection. Two caveats: work the caller enqueues on the ctx's stream OUTSIDE this API does not see deferred
- * projections (call paris_hip_flush first), and paris_hip_ctx_destroy discards what is still pending. Depth 1 (the
+ * projections (call paris_hip_flush first), and paris_hip_ctx_destroy runs what is still pending only if the volume is still a live
+ * device allocation (it is dropped otherwise). Depth 1 (the
  * default) is immediate execution. The C++ mirror paris::hip enables depth 16, so PARIS's unchanged per-projection loop
  * (src/main.cpp:98-105) runs at the fused kernel's rate. */
 int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t depth);

@@ -4,6 +4,9 @@
  * TEST INFRASTRUCTURE ONLY (see paris_oracle.h). Parity pin: the known-answer values of
  * SURVEY.md section 8c (tests/test_oracle_kat.py); the reference itself cannot be built in this image
  * (it needs fftw3.h, Boost.Log and GLADOS, none of which is installed), see DESIGN.md.
+ * PARITY UNPINNED in the strict sense: the reference holds no tests, fixtures or golden vectors for this path, and the
+ * section-8c values were recorded from a survey-session build of the reference's OpenMP sources against stand-in
+ * fftw3.h / Boost.Log headers with MKL's FFTW3 interface -- not from anything the reference ships or that can be re-run here.
  *
  * Citations are reference file:line, relative to /root/reference.
  */

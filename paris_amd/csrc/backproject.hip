@@ -753,7 +753,7 @@ int paris_hip_flush_deferred(paris_hip_ctx* ctx)
     ctx->defer_count = 0; // first: batch_impl may fall back to single launches, which must not be deferred again
     const uint32_t depth = ctx->defer_depth;
     ctx->defer_depth = 1;
-    const int rc = batch_impl(ctx, ctx->defer_ring, false, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
+    const int rc = batch_impl(ctx, ctx->defer_ring, ctx->defer_f16, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
                               ctx->defer_dim_y, ctx->key_v, ctx->key_dims[0], ctx->key_dims[1], ctx->key_dims[2], ctx->key_dims[3],
                               &ctx->key_det, &ctx->key_vol, ctx->key_enable_roi, &ctx->key_roi, ctx->defer_sin.data(),
                               ctx->defer_cos.data(), ctx->key_delta_s, ctx->key_delta_t);
@@ -761,7 +761,7 @@ int paris_hip_flush_deferred(paris_hip_ctx* ctx)
     return rc;
 }
 
-static int defer_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitch, uint32_t p_dim_x, uint32_t p_dim_y, float* d_v,
+static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, uint32_t p_dim_x, uint32_t p_dim_y, float* d_v,
                              uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
                              const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
                              const paris_region_of_interest* roi, float sin_phi, float cos_phi, float delta_s, float delta_t)
@@ -769,11 +769,12 @@ static int defer_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitc
     // the checks of an immediate call, so that a bad argument is reported by the call that made it
     BpParams g;
     bool fd = false, skip = false;
-    if(int rc = fill_params(ctx, d_p, false, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
+    if(int rc = fill_params(ctx, d_p, f16, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
                             enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t, g, fd, skip))
         return rc;
     if(skip)
         return paris_hip_finish(ctx);
+    const size_t px = f16 ? sizeof(uint16_t) : sizeof(float);
     const paris_region_of_interest no_roi{};
     const paris_region_of_interest& r = enable_roi ? *roi : no_roi;
     const uint32_t dims[4] = {v_dim_x, v_dim_y, v_dim_z, v_offset};
@@ -781,12 +782,12 @@ static int defer_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitc
                       && std::memcmp(&ctx->key_det, det_geo, sizeof(*det_geo)) == 0 && std::memcmp(&ctx->key_vol, vol_geo, sizeof(*vol_geo)) == 0
                       && ctx->key_enable_roi == (enable_roi ? 1 : 0) && std::memcmp(&ctx->key_roi, &r, sizeof(r)) == 0
                       && std::memcmp(&ctx->key_delta_s, &delta_s, sizeof(float)) == 0 && std::memcmp(&ctx->key_delta_t, &delta_t, sizeof(float)) == 0
-                      && ctx->defer_dim_x == p_dim_x && ctx->defer_dim_y == p_dim_y;
+                      && ctx->defer_dim_x == p_dim_x && ctx->defer_dim_y == p_dim_y && ctx->defer_f16 == f16;
     if(!same)
     {
         if(int rc = paris_hip_flush_deferred(ctx))
             return rc;
-        if(ctx->defer_dim_x != p_dim_x || ctx->defer_dim_y != p_dim_y || ctx->defer_slots < ctx->defer_depth)
+        if(ctx->defer_dim_x != p_dim_x || ctx->defer_dim_y != p_dim_y || ctx->defer_slots < ctx->defer_depth || ctx->defer_f16 != f16)
         {
             if(ctx->defer_ring != nullptr)
             {
@@ -794,7 +795,8 @@ static int defer_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitc
                 PARIS_HIP_TRY(hipFree(ctx->defer_ring));
                 ctx->defer_ring = nullptr;
             }
-            ctx->defer_pitch = (static_cast<size_t>(p_dim_x) * sizeof(float) + 255u) / 256u * 256u;
+            ctx->defer_pitch = (static_cast<size_t>(p_dim_x) * px + 255u) / 256u * 256u;
+            ctx->defer_f16 = f16;
             PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->defer_ring), ctx->defer_pitch * p_dim_y * ctx->defer_depth));
             ctx->defer_dim_x = p_dim_x;
             ctx->defer_dim_y = p_dim_y;
@@ -812,7 +814,7 @@ static int defer_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_pitc
         ctx->defer_cos.assign(ctx->defer_depth, 0.f);
     }
     char* slot = reinterpret_cast<char*>(ctx->defer_ring) + ctx->defer_pitch * p_dim_y * ctx->defer_count;
-    PARIS_HIP_TRY(hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * sizeof(float), p_dim_y,
+    PARIS_HIP_TRY(hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * px, p_dim_y,
                                    hipMemcpyDeviceToDevice, ctx->stream));
     if(int rc = paris_hip_note_projection_use(ctx, d_p, p_pitch * p_dim_y)) // the snapshot copy is the last reader of the caller's buffer
         return rc;
@@ -848,7 +850,7 @@ extern "C" int paris_hip_backproject(paris_hip_ctx* ctx, const float* d_p, size_
                                      float delta_t)
 {
     if(ctx != nullptr && ctx->defer_depth > 1 && (ctx->bp_variant == 0 || ctx->bp_variant == 4))
-        return defer_backproject(ctx, d_p, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
+        return defer_backproject(ctx, d_p, false, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
                                  enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
     return backproject_impl(ctx, d_p, false, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
                             enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
@@ -861,6 +863,9 @@ extern "C" int paris_hip_backproject_f16(paris_hip_ctx* ctx, const uint16_t* d_p
                                          const paris_region_of_interest* roi, float sin_phi, float cos_phi,
                                          float delta_s, float delta_t)
 {
+    if(ctx != nullptr && ctx->defer_depth > 1 && (ctx->bp_variant == 0 || ctx->bp_variant == 4))
+        return defer_backproject(ctx, d_p, true, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
+                                 enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t);
     if(int rc = paris_hip_flush_deferred(ctx))
         return rc;
     return backproject_impl(ctx, d_p, true, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,

@@ -118,6 +118,7 @@ struct paris_hip_ctx
     float* defer_ring = nullptr;
     size_t defer_pitch = 0;
     uint32_t defer_dim_x = 0, defer_dim_y = 0, defer_slots = 0;
+    bool defer_f16 = false; // the ring holds IEEE half pixels (calls through paris_hip_backproject_f16)
     float* key_v = nullptr;
     uint32_t key_dims[4] = {0, 0, 0, 0}; // v_dim_x, v_dim_y, v_dim_z, v_offset
     paris_detector_geometry key_det{};

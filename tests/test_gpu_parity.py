@@ -709,6 +709,36 @@ def test_backproject_f16_projections(be, oracle, kat_golden):
         assert_bit_equal(got, want)
 
 
+def test_backproject_f16_calls_are_deferred_too(oracle, kat_golden):
+    """paris_hip_backproject_f16 behind the deferral: 8 half-precision calls with depth 3 (groups of 3 + 3 + 2 at read-back),
+    one fp32 call in between (another precision: the pending half group is flushed first); bit-identical to immediate calls."""
+    det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
+    vg, ovg = B.calculate_volume_geometry(det), oracle.calculate_volume_geometry(odet)
+    frames = [kat_golden["filtered"][i] * np.float32(3.0) for i in range(8)]
+
+    def run(depth):
+        with B.Backend(0, synchronous=False) as abe:
+            abe.set_backproject_deferral(depth)
+            d_v = abe.make_volume_device(67, 67, 61)
+            for i, p in enumerate(frames):
+                d_p = to_device(abe, p, idx=i)
+                if i == 4:  # one fp32 call among the half ones
+                    B.backproject(abe, d_p, d_v, 0, det, vg, False, False, None)
+                else:
+                    h_ptr, h_pitch = abe.convert_projection_f16(d_p)
+                    s, c = B.stage_angle(det, i)
+                    abe.backproject_f16(h_ptr, h_pitch, 64, 48, d_v, 0, det, vg, False, None, s, c, det.delta_s * det.l_px_row,
+                                        det.delta_t * det.l_px_col)
+                    abe.free(h_ptr)  # released while the call is still pending: the ring holds the snapshot
+                abe.free(d_p)
+            return volume_to_host(abe, d_v)
+
+    rounded = [p if i == 4 else p.astype(np.float16).astype(np.float32) for i, p in enumerate(frames)]
+    want = oracle_backproject_all(oracle, rounded, odet, ovg, (61, 67, 67))
+    assert_bit_equal(run(1), want)
+    assert_bit_equal(run(3), want)
+
+
 @pytest.mark.parametrize("dims,roi_x2", [((21, 42, 72), 82), ((21, 42, 71), 81)])
 def test_backproject_f16_batch_bit_exact(be, oracle, dims, roi_x2):
     """paris_hip_backproject_batch_f16: the fused kernel on IEEE-half projections (one under the other in one buffer) equals
