@@ -250,6 +250,13 @@ def main():
                     "all-gather of per-slab checksums; slabs: the slabs themselves gathered on rank 0 (4 GiB each at N = 8)")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line and nothing else: libraries that print there from native code (RCCL's version banner at
+    # communicator creation, the ROCm runtime) are sent to stderr for the life of the process; the line is written to the
+    # saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -609,7 +616,8 @@ def main():
             out["config"]["rank_placement"] = placement
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     be.close()
     if dist is not None:

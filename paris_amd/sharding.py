@@ -51,7 +51,10 @@ def gather_placement(dist, dev_index, props=None):
                    or os.environ.get("CUDA_VISIBLE_DEVICES") or "",
     }
     for attr in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
-        v = getattr(props, attr, None) if props is not None else None
+        try:
+            v = getattr(props, attr, None) if props is not None else None
+        except Exception:  # a runtime that declares the property but cannot answer: fall back to (host, mask, index)
+            v = None
         if v is not None:
             mine[attr] = str(v)
     out = [None] * dist.get_world_size()
