@@ -464,9 +464,18 @@ int paris_hip_get_plan(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_plan** out)
         PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&plan.d_twiddle), tw.size() * sizeof(float2)));
         // one-off, tiny: a synchronous copy keeps the pageable staging vector alive long enough
         PARIS_HIP_TRY(hipMemcpy(plan.d_twiddle, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
-        it = ctx->plans.emplace(n, plan).first;
-        if(int rc = paris_hip_fused_filter_tables(ctx, n, &it->second)) // n >= 1024: the fused kernel's inter-pass twiddles
+        if(int rc = paris_hip_fused_filter_tables(ctx, n, &plan)) // n >= 1024: the fused kernel's inter-pass twiddles
+        {
+            // all or nothing: a plan with some of its tables missing must never reach a kernel
+            (void)hipFree(plan.d_twiddle);
+            if(plan.d_tab_first != nullptr)
+                (void)hipFree(plan.d_tab_first);
+            for(float2* t : plan.d_tab_mid)
+                if(t != nullptr)
+                    (void)hipFree(t);
             return rc;
+        }
+        it = ctx->plans.emplace(n, plan).first;
     }
     *out = &it->second;
     return PARIS_HIP_SUCCESS;

@@ -524,7 +524,13 @@ namespace
                 h[static_cast<size_t>(q - 1u) * sub + o] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
             }
         PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(out), h.size() * sizeof(float2)));
-        PARIS_HIP_TRY(hipMemcpy(*out, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice)); // one-off, small
+        const hipError_t err = hipMemcpy(*out, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice); // one-off, small
+        if(err != hipSuccess)
+        {
+            (void)hipFree(*out);
+            *out = nullptr;
+            return static_cast<int>(err);
+        }
         return PARIS_HIP_SUCCESS;
     }
 }
@@ -555,7 +561,13 @@ int paris_hip_fused_filter_permute_k(paris_hip_ctx* ctx, const float* d_k, uint3
 {
     PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(d_kp), static_cast<size_t>(n) * sizeof(float)));
     hipLaunchKernelGGL(permute_k_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, d_k, *d_kp, ilog2(n));
-    PARIS_HIP_TRY(hipGetLastError());
+    const hipError_t err = hipGetLastError();
+    if(err != hipSuccess)
+    {
+        (void)hipFree(*d_kp);
+        *d_kp = nullptr;
+        return static_cast<int>(err);
+    }
     return PARIS_HIP_SUCCESS;
 }
 
