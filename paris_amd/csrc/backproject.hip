@@ -536,6 +536,19 @@ int paris_hip_prevalidate_fast_division(paris_hip_ctx* ctx, float l_px_row, floa
     return fastdiv_is_exact(ctx, l_px_col, &ok);
 }
 
+// Cache policy of the volume stream: 0 plain, 1 nontemporal, 2 nontemporal loads + write-through nontemporal stores. Automatic
+// (ctx->bp_nt < 0): a slab that (mostly) stays in the 256 MiB Infinity Cache between launches must not be pushed out to HBM by
+// nontemporal / write-through accesses -- plain accesses are faster up to about 400 MiB (256^3: 27.3 against 32.8 us per launch,
+// 384^3 = 216 MiB: 71.8 against 92.0, 448^3 = 343 MiB: 128 against 142; 512^3 = 512 MiB: 221 against 212:
+// profiles/r02_cache_policy_by_size.txt); anything larger is touched once per launch and streams best with policy 2.
+static int volume_stream_policy(const paris_hip_ctx* ctx, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z)
+{
+    if(ctx->bp_nt >= 0)
+        return ctx->bp_nt;
+    const uint64_t bytes = 4ull * v_dim_x * v_dim_y * v_dim_z;
+    return bytes <= (384ull << 20) ? 0 : 2;
+}
+
 // validates the arguments of one backprojection and derives the kernel parameters; *skip = true for an empty volume
 static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, uint32_t p_dim_x, uint32_t p_dim_y,
                        float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
@@ -623,7 +636,7 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     g.tz = tz;
     // default mapping: see the tile depth above (a y band per XCD beyond 1024^2 planes, a contiguous run of tiles per XCD below)
     g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 12u : 5u);
-    g.store_sc1 = ctx->bp_nt == 2 ? 1u : 0u;
+    g.store_sc1 = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) == 2 ? 1u : 0u;
     // 4-pixel staging needs every detector row to start 16-byte (half: 8-byte) aligned
     g.stage_vec4 = (ctx->bp_stage_vec4 != 0 && g.p_pitch % 4u == 0 && reinterpret_cast<uintptr_t>(d_p) % (4u * px) == 0)
                        ? 1u : 0u;
@@ -669,7 +682,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         fp.cos_phi[0] = cos_phi;
         const int width = lane_width(d_v, v_dim_x);
         const int vx = ctx->bp_vx == 4 && width == 4 ? 4 : (ctx->bp_vx == 1 || width < 2 ? 1 : 2);
-        paris_hip_bp_launch_fused(&fp, vx, ctx->bp_tz == 8u ? 8 : 16, ctx->bp_nt != 0, fd, ctx->stream);
+        paris_hip_bp_launch_fused(&fp, vx, ctx->bp_tz == 8u ? 8 : 16, volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) != 0, fd, ctx->stream);
     }
     else
     if(ctx->bp_variant == 1)
@@ -687,7 +700,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         // slices in flight per lane: 2 (interleaved A/B on 2048^3: tools/ab_bp.py, profiles/); with the 8-slice tiles of
         // 1024^2 planes one slice plus the prefetch of the next is as fast and leaves more registers
         const int unroll = ctx->bp_unroll ? ctx->bp_unroll : (g.tz == 8u && ctx->bp_tz == 0u ? 1 : 2);
-        const bool nt = ctx->bp_nt != 0;
+        const bool nt = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) != 0;
         const bool want_slice = ctx->bp_variant == 3; // measured slower than the tile kernel so far: opt-in only
         if(want_slice && vx == 4)
         {
@@ -979,7 +992,7 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         return paris_hip_finish(ctx);
     }
 
-    const bool nt = ctx->bp_nt != 0;
+    const bool nt = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) != 0;
     const bool tz16 = ctx->bp_tz != 8u; // 16 slices per tile unless 8 is asked for (tools/tune_bp.py --fused)
     for(uint32_t first = 0; first < n_proj; first += FUSED_MAX)
     {
@@ -1050,7 +1063,7 @@ extern "C" int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, in
     if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5 || order == 8 || order == 9 || order == 12) || nontemporal < -1 || nontemporal > 2)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_order = order;
-    ctx->bp_nt = nontemporal < 0 ? 2 : nontemporal;
+    ctx->bp_nt = nontemporal; // < 0: automatic (by slab size)
     return PARIS_HIP_SUCCESS;
 }
 

@@ -53,7 +53,7 @@ struct paris_hip_ctx
     uint32_t bp_tz = 0, bp_lds_bytes = 0;
     int bp_order = -1; // -1 = default mapping
     int bp_slice_nw = 0, bp_slice_rpl = 0; // slice kernel shape, 0 = default
-    int bp_nt = 2;     // volume stream policy: 0 default, 1 nontemporal, 2 nontemporal + write-through stores
+    int bp_nt = -1;    // volume stream policy: -1 automatic by slab size, 0 plain, 1 nontemporal, 2 nontemporal + write-through stores
     int bp_stage_vec4 = 1; // stage the detector box 4 pixels per lane when the projection's alignment allows
     int bp_fastdiv = 1; // use the validated multiply+2 FMA division by the pixel pitch when it is exact
     std::map<uint32_t, bool> fastdiv_exact; // divisor bits -> exhaustive check result
