@@ -101,3 +101,22 @@ def test_two_rank_rehearsal_filter_sharding():
     assert sharded["final_gather"]["slab_checksums"] == plain["final_gather"]["slab_checksums"]
     assert len(sharded["final_gather"]["slab_checksums"]) == 2 and sharded["value"] > 0
     assert sharded["roofline"]["launches_timed"] == 7
+
+
+def test_one_rank_under_torchrun_with_rccl_prints_only_the_json_line():
+    """The driver launches N > 1 through torch.distributed.run with the nccl (= RCCL) backend; RCCL prints a version banner on
+    stdout from native code when the communicator is created. bench.py must keep stdout to its ONE JSON line (everything
+    else goes to stderr). One rank on the one GPU exercises the same code: process group, placement gathering, barrier,
+    all-reduce of the elapsed time."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload",
+                        "c1", "--steps", "2", "--warmup", "1", "--cpu-budget", "0", "--fused-steps", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["rank_placement"][0]["rank"] == 0 and "final_gather" not in d
