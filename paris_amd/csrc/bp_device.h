@@ -251,6 +251,10 @@ namespace
         int bw;       // staged columns (0: nothing staged)
         int bhs;      // staged rows
         int stride;   // LDS row stride in floats (odd)
+        // row bounds of the box as floats for make_column's tests (workgroup-uniform): a column's valid taps are inside the box iff
+        // v_min >= row_lo and v_max < row_hi, where the bound is infinite on a side on which the box reaches the detector's edge
+        float row_lo, row_hi;
+        float first_row, end_row; // by0 and by0 + bhs - 1 as floats: every tap (valid or not) inside iff first_row <= v < end_row
     };
 
     // Detector bounding box of the voxel tile [k0,k1] x [l0,l1] x [m0,m1]. h is a projective function of (x,y) and
@@ -335,6 +339,10 @@ namespace
             b.bhs = 0;
             b.stride = 1;
         }
+        b.first_row = static_cast<float>(b.by0);
+        b.end_row = static_cast<float>(b.by0 + b.bhs - 1);
+        b.row_lo = b.by0 == 0 ? -INFINITY : b.first_row;
+        b.row_hi = (b.by0 + b.bhs >= static_cast<int>(g.p_dim_y)) ? INFINITY : b.end_row;
         return b;
     }
 
@@ -452,17 +460,22 @@ namespace
         const float va = v_coordinate<FD>(g, z_first, c.factor);
         const float vb = v_coordinate<FD>(g, z_last, c.factor);
         const bool ordered = (va == va) && (vb == vb); // no NaN
-        const int r_lo = max(static_cast<int>(floorf(fminf(va, vb))), 0);                              // valid taps start at row 0
-        const int r_hi = min(static_cast<int>(floorf(fmaxf(va, vb))), static_cast<int>(g.p_dim_y) - 2); // and end at dim_y - 2
-        const bool rows_inside = (r_lo > r_hi) || (r_lo >= b.by0 && r_hi <= b.by0 + b.bhs - 2);
+        // Valid taps have their upper row in [0, dim_y - 2]. With r_lo = max(floor(v_min), 0) and r_hi = min(floor(v_max), dim_y - 2) the
+        // column's valid rows are inside the box iff r_lo > r_hi (none) or by0 <= r_lo and r_hi <= by0 + bhs - 2. In floats, for
+        // integers n: floor(v) >= n <=> v >= n and floor(v) <= n <=> v < n + 1, so
+        //   none      <=> v_max < 0 or v_min >= dim_y - 1
+        //   r_lo >= by0           <=> v_min >= by0 or by0 == 0            (= v_min >= row_lo)
+        //   r_hi <= by0 + bhs - 2 <=> v_max < by0 + bhs - 1 or the box reaches the last row (= v_max < row_hi)
+        // (infinite coordinates compare like the saturating conversions did; NaN is excluded by `ordered`)
+        const float v_min = fminf(va, vb), v_max = fmaxf(va, vb);
+        const bool rows_inside = (v_max < 0.f) || (v_min >= g.p_dim_y_f - 1.f) || (v_min >= b.row_lo && v_max < b.row_hi);
         const bool finite_factor = (c.factor - c.factor) == 0.f; // with a finite factor v is never NaN (it may overflow to inf)
         col.fast = !x_valid || (ordered && finite_factor && col.xoff >= 0 && rows_inside);
         // All taps valid: the unclamped rows of both end slices lie in [by0, by0 + bhs - 2] (the box is clipped to the detector, so
         // a row pair inside it is a valid pair). floor(v) >= by0 <=> v >= by0 and floor(v) <= by0 + bhs - 2 <=> v < by0 + bhs - 1
         // for the integers by0, bhs; a NaN fails both comparisons. By the monotonicity argument above every slice in between is
         // inside too: such a column needs neither the per-voxel validity test nor the row clamp nor the final select.
-        col.inside = x_valid && finite_factor && col.xoff >= 0 && b.bhs >= 2
-                     && fminf(va, vb) >= static_cast<float>(b.by0) && fmaxf(va, vb) < static_cast<float>(b.by0 + b.bhs - 1);
+        col.inside = x_valid && finite_factor && col.xoff >= 0 && b.bhs >= 2 && v_min >= b.first_row && v_max < b.end_row;
         return col;
     }
 
