@@ -630,6 +630,16 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
             return rc;
         fd = fd && fd_x;
     }
+    {
+        // lean_div (bp_device.h: column_constants): every denominator s + d_so of this launch lies in [0.1, 1.9] x d_so -- the slab's
+        // (x, y) extent stays within 0.9 d_so of the axis, |s| <= hypot(max |x|, max |y|) -- and d_so, d_sd are ordinary numbers
+        const double x0 = g.x_base + static_cast<double>(g.k_off) * g.l_vx_x, x1 = g.x_base + (static_cast<double>(g.k_off) + v_dim_x - 1.0) * g.l_vx_x;
+        const double y0 = g.y_base + static_cast<double>(g.l_off) * g.l_vx_y, y1 = g.y_base + (static_cast<double>(g.l_off) + v_dim_y - 1.0) * g.l_vx_y;
+        const double reach = std::hypot(std::max(std::fabs(x0), std::fabs(x1)), std::max(std::fabs(y0), std::fabs(y1)));
+        const double lo = std::ldexp(1.0, -40), hi = std::ldexp(1.0, 40);
+        const bool ordinary = g.d_so >= lo && g.d_so <= hi && g.d_sd >= lo && g.d_sd <= hi;
+        g.lean_div = (ctx->bp_lean_div != 0 && ordinary && std::isfinite(reach) && reach <= 0.9 * g.d_so) ? 1u : 0u;
+    }
     g.p_dim_x_f = static_cast<float>(p_dim_x);
     g.p_dim_y_f = static_cast<float>(p_dim_y);
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
@@ -1096,6 +1106,7 @@ extern "C" int paris_hip_set_backproject_fast_division(paris_hip_ctx* ctx, int e
         return rc;
     if(ctx == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    ctx->bp_lean_div = enable ? 1 : 0; // the shared-reciprocal form of the two per-column divisions follows the same switch
     ctx->bp_fastdiv = enable ? 1 : 0;
     return PARIS_HIP_SUCCESS;
 }

@@ -56,6 +56,7 @@ struct paris_hip_ctx
     int bp_nt = -1;    // volume stream policy: -1 automatic by slab size, 0 plain, 1 nontemporal, 2 nontemporal + write-through stores
     int bp_stage_vec4 = 1; // stage the detector box 4 pixels per lane when the projection's alignment allows
     int bp_fastdiv = 1; // use the validated multiply+2 FMA division by the pixel pitch when it is exact
+    int bp_lean_div = 1; // share one reciprocal between the two per-column divisions by s + d_so when the operands are in range
     std::map<uint32_t, bool> fastdiv_exact; // divisor bits -> exhaustive check result
     bool filter_lds_attr_set = false;
     bool filter_r16_attr_set[5] = {false, false, false, false, false}; // LOG2N 10..14

@@ -645,6 +645,41 @@ def test_backproject_detector_edges_and_empty_views(be, oracle):
             (np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)]))
 
 
+@pytest.mark.parametrize("reach_over_d_so", [0.5, 0.89, 0.91, 1.3])
+@pytest.mark.parametrize("fused", [False, True])
+def test_backproject_shared_reciprocal_division_range(be, oracle, reach_over_d_so, fused):
+    """The two per-column divisions by s + d_so share one reciprocal only while every denominator of the launch stays in
+    [0.1, 1.9] d_so (bp_device.h column_constants, backproject.hip fill_params); beyond that -- here the grid is scaled until
+    its corner passes 0.9 d_so and then the source itself, denominators near and below zero -- the IEEE sequence runs. Same
+    bits as the oracle on both sides of the switch, per-projection and fused launches."""
+    g = (48, 40, 0.4, 0.4, 1.0, -2.0, 90, 60, 29.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    dims = (24, 40, 44)
+    dz, dy, dx = dims
+    corner = np.hypot(dx / 2.0, dy / 2.0)
+    l_vx = float(np.float32(reach_over_d_so * 90.0 / corner))
+    vg = B.VolumeGeometry(dx, dy, dz, l_vx, l_vx, l_vx)
+    ovg = oracle.VolumeGeometry(dx, dy, dz, l_vx, l_vx, l_vx)
+    projs = [oracle.lcg_projection(48, 40, i) for i in range(12)]
+    want = oracle_backproject_all(oracle, projs, odet, ovg, dims)
+    if fused:
+        n, rows, cols = 12, 40, 48  # n_row = pixels per detector row
+        stack = be.make_projection_device(cols, rows * n)
+        be.copy_h2d(B.Projection(np.ascontiguousarray(np.stack(projs).reshape(n * rows, cols)), cols, rows * n), stack)
+        sc = [B.stage_angle(det, i) for i in range(n)]
+        d_v = be.make_volume_device(dx, dy, dz)
+        be.backproject_batch(stack.ptr, stack.pitch, stack.pitch * rows, n, cols, rows, d_v, 0, det, vg, False, None,
+                             [s_ for s_, _ in sc], [c_ for _, c_ in sc], det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
+        got = volume_to_host(be, d_v)
+        be.free(d_v)
+        be.free(stack)
+    else:
+        got = hip_backproject_all(be, projs, det, vg, dims)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
+
+
 def test_backproject_with_angle_file_values(be, oracle):
     """enable_angles: phi comes from projection::phi instead of idx * delta_phi (src/backprojection.cpp:52-57)."""
     det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
