@@ -16,9 +16,16 @@ namespace
     // 0.93 TVox/s on the 2048^3 volume), 168 with a few cold-path spills (3 waves, 1.16); 2 voxels per lane run at 4 waves
     // without spills (1.30; a fifth wave adds nothing); 1 voxel per lane fits 7 but pays more staging per voxel (1.16). The base value below is the
     // 4-voxel / 16-slice case; narrower lanes and 8-slice tiles add to it.
+#ifndef PARIS_FUSED_PIPELINE
+#define PARIS_FUSED_PIPELINE 1
+#endif
 #ifndef PARIS_FUSED_WAVES
 #define PARIS_FUSED_WAVES 3
 #endif
+    // LDS row stride the kernel prefers (floats; 4 x 33: rows 16-byte aligned, consecutive rows start 4 banks apart): boxes up to
+    // 128 pixels wide -- the 64-column tile at magnifications up to about 2 -- take it, wider ones keep their own stride
+    constexpr int FIXED_STRIDE = 132;
+
     template <int VX, int TZ, bool NT, bool FD>
     __global__ void __launch_bounds__(256, PARIS_FUSED_WAVES + (VX == 2 ? 1 : VX == 1 ? (TZ == 32 ? 1 : 4) : 0) + (TZ == 8 ? 1 : 0)) bp_fused_kernel(const FusedParams fp)
     {
@@ -68,7 +75,7 @@ namespace
             g.sin_phi = fp.sin_phi[p];
             g.cos_phi = fp.cos_phi[p];
             g.proj = base + static_cast<size_t>(p) * fp.proj_stride * px;
-            const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats);
+            const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats, FIXED_STRIDE);
             __syncthreads(); // the previous projection's taps are done with the LDS box
             stage_box(g, box, lds, wave, 4u, lane);
             __syncthreads();
@@ -83,10 +90,41 @@ namespace
                     all_fast = all_fast && col[j].fast;
                     all_inside = all_inside && col[j].inside;
                 }
-                auto add_projection = [&](auto fast_tag, auto full_tag, auto inside_tag) {
+                auto add_projection = [&](auto fast_tag, auto full_tag, auto inside_tag, auto stride_tag) {
                     constexpr bool FAST = decltype(fast_tag)::value;
                     constexpr bool FULL = decltype(full_tag)::value; // whole tile: no per-slice test, one straight block
                     constexpr bool INSIDE = decltype(inside_tag)::value; // every tap valid: no validity test, clamp or select
+                    constexpr int CS = decltype(stride_tag)::value;      // the box has the compile-time row stride
+                    if constexpr(FAST && FULL && PARIS_FUSED_PIPELINE)
+                    {
+                        // two-stage pipeline over the slices: the LDS reads of slice z + 1 are in flight while slice z is finished
+                        Tap cur[VX];
+#pragma unroll
+                        for(int j = 0; j < VX; ++j)
+                            cur[j] = fetch_tap<FD, INSIDE, CS>(g, box, lds, g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z, col[j]);
+#pragma unroll
+                        for(int z = 0; z < TZ; ++z)
+                        {
+                            Tap next[VX];
+                            if(z + 1 < TZ)
+                            {
+                                const float z_n = g.z_base + static_cast<float>(g.m_off + m0 + z + 1) * g.l_vx_z; // :118
+#pragma unroll
+                                for(int j = 0; j < VX; ++j)
+                                    next[j] = fetch_tap<FD, INSIDE, CS>(g, box, lds, z_n, col[j]);
+                            }
+#pragma unroll
+                            for(int j = 0; j < VX; ++j)
+                                elem<VX>(acc[z], j) += finish_tap<INSIDE>(col[j], cur[j]);
+                            if(z + 1 < TZ)
+                            {
+#pragma unroll
+                                for(int j = 0; j < VX; ++j)
+                                    cur[j] = next[j];
+                            }
+                        }
+                        return;
+                    }
 #pragma unroll
                     for(int z = 0; z < TZ; ++z)
                     {
@@ -95,21 +133,28 @@ namespace
                             const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + z) * g.l_vx_z; // :118
 #pragma unroll
                             for(int j = 0; j < VX; ++j)
-                                elem<VX>(acc[z], j) += voxel_contribution<FD, FAST, INSIDE>(g, box, lds, z_m, col[j]);
+                                elem<VX>(acc[z], j) += voxel_contribution<FD, FAST, INSIDE, CS>(g, box, lds, z_m, col[j]);
                         }
                     }
                 };
                 // Wave-uniform choice of the all-valid path (a wave with one boundary lane takes the fast path for all its lanes:
                 // a per-lane branch would run both bodies). Interior tiles -- most of the field of view -- take it.
-                const bool wave_inside = mcount == TZ && __all(all_inside ? 1 : 0) != 0;
-                if(wave_inside)
-                    add_projection(std::true_type{}, std::true_type{}, std::true_type{});
+                const bool wave_inside = mcount == TZ && g.p_dim_y < (1u << 23) && __all(all_inside ? 1 : 0) != 0;
+                const bool fixed = box.stride == FIXED_STRIDE; // workgroup-uniform
+                using no_stride = std::integral_constant<int, 0>;
+                using the_stride = std::integral_constant<int, FIXED_STRIDE>;
+                if(wave_inside && fixed)
+                    add_projection(std::true_type{}, std::true_type{}, std::true_type{}, the_stride{});
+                else if(wave_inside)
+                    add_projection(std::true_type{}, std::true_type{}, std::true_type{}, no_stride{});
+                else if(all_fast && mcount == TZ && fixed)
+                    add_projection(std::true_type{}, std::true_type{}, std::false_type{}, the_stride{});
                 else if(all_fast && mcount == TZ)
-                    add_projection(std::true_type{}, std::true_type{}, std::false_type{});
+                    add_projection(std::true_type{}, std::true_type{}, std::false_type{}, no_stride{});
                 else if(all_fast)
-                    add_projection(std::true_type{}, std::false_type{}, std::false_type{});
+                    add_projection(std::true_type{}, std::false_type{}, std::false_type{}, no_stride{});
                 else
-                    add_projection(std::false_type{}, std::false_type{}, std::false_type{});
+                    add_projection(std::false_type{}, std::false_type{}, std::false_type{}, no_stride{});
             }
         }
 #pragma unroll

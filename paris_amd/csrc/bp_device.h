@@ -284,8 +284,11 @@ namespace
     // parallel and min/max-reduced with two butterfly shuffles (every wave computes the same box). The box is
     // widened by the taps' reach plus one pixel of rounding slack, clipped to the detector and cut to the LDS
     // budget; a tap that still falls outside is served from global memory, so this only has to be right for speed.
+    // prefer_stride (floats, a multiple of 4 and an odd one; 0: none): the stride to use whenever the box is no wider and all its
+    // rows still fit -- a kernel that knows the stride at compile time addresses both rows of a tap from one register
+    // (ds_read2_b32 with the row stride in its second offset, voxel_contribution<..., CS>).
     __device__ __forceinline__ Box tile_box(const BpParams& g, uint32_t k0, uint32_t k1, uint32_t l0, uint32_t l1,
-                                            uint32_t m0, uint32_t m1, uint32_t lane, uint32_t box_floats)
+                                            uint32_t m0, uint32_t m1, uint32_t lane, uint32_t box_floats, int prefer_stride = 0)
     {
         const uint32_t ci = lane & 3u;
         // The box only has to be right for speed (a tap outside it takes the global path, and whether a column may skip the
@@ -350,6 +353,8 @@ namespace
             b.stride = b.bw + 4;
             if(((b.stride >> 2) & 1) == 0)
                 b.stride += 4;
+            if(prefer_stride != 0 && b.stride <= prefer_stride && bh <= static_cast<int>(box_floats) / prefer_stride)
+                b.stride = prefer_stride;
         }
         else
             b.stride = b.bw | 1;
@@ -505,11 +510,13 @@ namespace
     // FAST: the column was proven to stay inside the staged box (Column::fast), so the global-memory path and its
     // branch are compiled out and the body is straight-line code the scheduler can overlap across voxels.
     // ALLVALID (implies FAST): the column was proven to have every tap valid and inside the box (Column::inside)
-    template <bool FD, bool FAST, bool ALLVALID = false>
+    // CS: the LDS row stride in floats when the kernel fixed it at compile time (b.stride == CS), else 0
+    template <bool FD, bool FAST, bool ALLVALID = false, int CS = 0>
     __device__ __forceinline__ float voxel_contribution(const BpParams& g, const Box& b, const float* lds_box, float z_m,
                                                         const Column& col)
     {
         static_assert(!ALLVALID || FAST, "ALLVALID is a refinement of FAST");
+        static_assert(CS >= 0 && CS < 255, "both rows of a tap must be within reach of one ds_read2_b32");
         const float v = v_coordinate<FD>(g, z_m, col.factor);
         float y1 = 0.f, y2 = 0.f;
         int y1i;
@@ -552,12 +559,21 @@ namespace
         // v_mul_lo_u32 is quarter rate) and the row below one add. Integer addresses keep the compiler from adding the
         // (zero) link-time base of the dynamic LDS array to every access.
         using lds_cptr = const __attribute__((address_space(3))) float*;
-        const int stride4 = b.stride << 2;
+        const int stride4 = (CS != 0 ? CS : b.stride) << 2;
         const uint32_t xaddr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_box)) + (static_cast<uint32_t>(max(col.xoff, 0)) << 2);
-        const uint32_t a1 = static_cast<uint32_t>(__mul24(rc, stride4)) + xaddr;
-        const uint32_t a2 = a1 + static_cast<uint32_t>(stride4);
+        // ALLVALID: no clamp, so the box's first row folds into the z-invariant term as well (wrapping 32-bit arithmetic; the
+        // kernel takes this path only for detectors of fewer than 2^23 rows, the reach of the 24-bit multiply)
+        uint32_t a1;
+        if(ALLVALID)
+        {
+            uint32_t xrel = xaddr - static_cast<uint32_t>(__mul24(b.by0, stride4));
+            asm("" : "+v"(xrel)); // opaque: keeps the compiler from refactoring into (y1i - by0) * stride4, one more instruction per tap
+            a1 = static_cast<uint32_t>(__mul24(y1i, stride4)) + xrel;
+        }
+        else
+            a1 = static_cast<uint32_t>(__mul24(rc, stride4)) + xaddr;
         lds_cptr r1 = reinterpret_cast<lds_cptr>(a1);
-        lds_cptr r2 = reinterpret_cast<lds_cptr>(a2);
+        lds_cptr r2 = CS != 0 ? r1 + CS : reinterpret_cast<lds_cptr>(a1 + static_cast<uint32_t>(stride4));
         float q11 = r1[0];
         float q21 = r1[1];
         float q12 = r2[0];
@@ -588,6 +604,65 @@ namespace
         float det = wy2 * interp_y1 + wy1 * interp_y2;
         if(!ALLVALID)
             det = valid ? det : 0.f;     // :71
+        return 0.5f * det * col.u * col.u; // :140
+    }
+
+    // voxel_contribution<FD, true, ALLVALID, CS> in two halves, for a slice loop that issues the LDS reads of the next slice before it
+    // finishes the current one (the fused kernel: a wave otherwise sits out one LDS round trip per voxel-update). Same
+    // operations on the same values in the same order per voxel; only the interleaving across voxels differs.
+    struct Tap
+    {
+        float q11, q21, q12, q22; // the four detector pixels
+        float wy1;                // row weight of the lower pair
+        bool valid;
+    };
+
+    template <bool FD, bool ALLVALID, int CS>
+    __device__ __forceinline__ Tap fetch_tap(const BpParams& g, const Box& b, const float* lds_box, float z_m, const Column& col)
+    {
+        Tap t;
+        const float v = v_coordinate<FD>(g, z_m, col.factor);
+        int y1i;
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(y1i) : "v"(v));
+        t.wy1 = __builtin_amdgcn_fractf(v);
+        using lds_cptr = const __attribute__((address_space(3))) float*;
+        const int stride4 = (CS != 0 ? CS : b.stride) << 2;
+        const uint32_t xaddr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_box)) + (static_cast<uint32_t>(max(col.xoff, 0)) << 2);
+        uint32_t a1;
+        if(ALLVALID)
+        {
+            t.valid = true;
+            uint32_t xrel = xaddr - static_cast<uint32_t>(__mul24(b.by0, stride4));
+            asm("" : "+v"(xrel));
+            a1 = static_cast<uint32_t>(__mul24(y1i, stride4)) + xrel;
+        }
+        else
+        {
+            const int rrel = y1i - b.by0;
+            const unsigned rowlim = col.ymax > 0.f ? static_cast<unsigned>(max(b.bhs - 1, 0)) : 0u;
+            t.valid = static_cast<unsigned>(rrel) < rowlim;
+            int rc;
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(rc) : "v"(rrel), "v"(max(b.bhs - 2, 0)));
+            a1 = static_cast<uint32_t>(__mul24(rc, stride4)) + xaddr;
+        }
+        lds_cptr r1 = reinterpret_cast<lds_cptr>(a1);
+        lds_cptr r2 = CS != 0 ? r1 + CS : reinterpret_cast<lds_cptr>(a1 + static_cast<uint32_t>(stride4));
+        t.q11 = r1[0];
+        t.q21 = r1[1];
+        t.q12 = r2[0];
+        t.q22 = r2[1];
+        return t;
+    }
+
+    template <bool ALLVALID>
+    __device__ __forceinline__ float finish_tap(const Column& col, const Tap& t)
+    {
+        const float interp_y1 = col.wx2 * t.q11 + col.wx1 * t.q21; // :77
+        const float interp_y2 = col.wx2 * t.q12 + col.wx1 * t.q22; // :78
+        const float wy2 = 1.f - t.wy1;
+        float det = wy2 * interp_y1 + t.wy1 * interp_y2;
+        if(!ALLVALID)
+            det = t.valid ? det : 0.f;     // :71
         return 0.5f * det * col.u * col.u; // :140
     }
 
