@@ -70,13 +70,17 @@ namespace
         // isolation when no source is a scalar register, tools/pkbench.hip -- was measured: no gain in this instruction mix.)
         const char* base = static_cast<const char*>(fp.g.proj);
         const size_t px = g.proj_f16 ? 2u : 4u;
+        // the detector boxes of all projections of this tile, 16 per wave at once (waves 0 and 1: FUSED_MAX = 32)
+        __shared__ int box_tab[FUSED_MAX * BOX_WORDS];
+        if(wave * 16u < fp.n_proj && wave < 2u)
+            tile_boxes_to_lds(g, fp.sin_phi, fp.cos_phi, wave * 16u, fp.n_proj, k0, k1, l0, l1, m0, m1, lane, g.lds_floats, FIXED_STRIDE, box_tab);
         for(uint32_t p = 0; p < fp.n_proj; ++p)
         {
             g.sin_phi = fp.sin_phi[p];
             g.cos_phi = fp.cos_phi[p];
             g.proj = base + static_cast<size_t>(p) * fp.proj_stride * px;
-            const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats, FIXED_STRIDE);
-            __syncthreads(); // the previous projection's taps are done with the LDS box
+            __syncthreads(); // the previous projection's taps are done with the LDS box (p == 0: the table of boxes is written)
+            const Box box = box_from_lds(box_tab, p, lane);
             stage_box(g, box, lds, wave, 4u, lane);
             __syncthreads();
             if(active)

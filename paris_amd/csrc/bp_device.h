@@ -287,24 +287,27 @@ namespace
     // prefer_stride (floats, a multiple of 4 and an odd one; 0: none): the stride to use whenever the box is no wider and all its
     // rows still fit -- a kernel that knows the stride at compile time addresses both rows of a tap from one register
     // (ds_read2_b32 with the row stride in its second offset, voxel_contribution<..., CS>).
-    __device__ __forceinline__ Box tile_box(const BpParams& g, uint32_t k0, uint32_t k1, uint32_t l0, uint32_t l1,
-                                            uint32_t m0, uint32_t m1, uint32_t lane, uint32_t box_floats, int prefer_stride = 0)
+    // the four extents of the box as integers, identical in the four lanes of a group of lanes 4i .. 4i + 3 (which share sin_phi and
+    // cos_phi); different groups may evaluate different projections
+    struct BoxExtents
+    {
+        int hmin, hmax, vmin, vmax;
+    };
+
+    __device__ __forceinline__ BoxExtents tile_box_extents(const BpParams& g, float sin_phi, float cos_phi, uint32_t k0, uint32_t k1,
+                                                           uint32_t l0, uint32_t l1, uint32_t m0, uint32_t m1, uint32_t lane)
     {
         const uint32_t ci = lane & 3u;
         // The box only has to be right for speed (a tap outside it takes the global path, and whether a column may skip the
         // per-tap check is decided from the exact coordinates in make_column), so the corner rays are evaluated with the
         // hardware reciprocal instead of three IEEE divisions: ~2e-7 relative, far inside the one pixel of slack below.
-        ColConst c;
-        {
-            const float x_k = g.x_base + static_cast<float>(g.k_off + ((ci & 1u) ? k1 : k0)) * g.l_vx_x;
-            const float y_l = g.y_base + static_cast<float>(g.l_off + ((ci & 2u) ? l1 : l0)) * g.l_vx_y;
-            const float s = x_k * g.cos_phi + y_l * g.sin_phi;
-            const float t = -x_k * g.sin_phi + y_l * g.cos_phi;
-            c.factor = g.d_sd * __builtin_amdgcn_rcpf(s + g.d_so);
-            c.h = ((t * c.factor) - g.min_h) * g.rcp_l_px_x - (1.f / 2.f);
-            c.u = 0.f;
-        }
-        float hmin = c.h, hmax = c.h, fmin = c.factor, fmax = c.factor;
+        const float x_k = g.x_base + static_cast<float>(g.k_off + ((ci & 1u) ? k1 : k0)) * g.l_vx_x;
+        const float y_l = g.y_base + static_cast<float>(g.l_off + ((ci & 2u) ? l1 : l0)) * g.l_vx_y;
+        const float s = x_k * cos_phi + y_l * sin_phi;
+        const float t = -x_k * sin_phi + y_l * cos_phi;
+        const float factor = g.d_sd * __builtin_amdgcn_rcpf(s + g.d_so);
+        const float h = ((t * factor) - g.min_h) * g.rcp_l_px_x - (1.f / 2.f);
+        float hmin = h, hmax = h, fmin = factor, fmax = factor;
 #pragma unroll
         for(int m = 1; m <= 2; m <<= 1)
         {
@@ -322,12 +325,19 @@ namespace
             vmin = fminf(vmin, __shfl_xor(vmin, m));
             vmax = fmaxf(vmax, __shfl_xor(vmax, m));
         }
-        // identical in every lane by construction; readfirstlane moves them to scalar registers
-        const int ihmin = __builtin_amdgcn_readfirstlane(to_int_clamped(hmin));
-        const int ihmax = __builtin_amdgcn_readfirstlane(to_int_clamped(hmax));
-        const int ivmin = __builtin_amdgcn_readfirstlane(to_int_clamped(vmin));
-        const int ivmax = __builtin_amdgcn_readfirstlane(to_int_clamped(vmax));
+        BoxExtents e;
+        e.hmin = to_int_clamped(hmin);
+        e.hmax = to_int_clamped(hmax);
+        e.vmin = to_int_clamped(vmin);
+        e.vmax = to_int_clamped(vmax);
+        return e;
+    }
 
+    // the extents widened by the taps' reach plus one pixel of rounding slack, clipped to the detector and cut to the LDS budget
+    // (integer arithmetic only: on scalar registers when the extents are uniform, per lane otherwise)
+    __device__ __forceinline__ Box box_of_extents(const BpParams& g, int ihmin, int ihmax, int ivmin, int ivmax, uint32_t box_floats,
+                                                  int prefer_stride)
+    {
         Box b;
         b.bx0 = max(ihmin - 1, 0);
         b.by0 = max(ivmin - 1, 0);
@@ -370,6 +380,69 @@ namespace
         b.end_row = static_cast<float>(b.by0 + b.bhs - 1);
         b.row_lo = b.by0 == 0 ? -INFINITY : b.first_row;
         b.row_hi = (b.by0 + b.bhs >= static_cast<int>(g.p_dim_y)) ? INFINITY : b.end_row;
+        return b;
+    }
+
+    __device__ __forceinline__ Box tile_box(const BpParams& g, uint32_t k0, uint32_t k1, uint32_t l0, uint32_t l1,
+                                            uint32_t m0, uint32_t m1, uint32_t lane, uint32_t box_floats, int prefer_stride = 0)
+    {
+        const BoxExtents e = tile_box_extents(g, g.sin_phi, g.cos_phi, k0, k1, l0, l1, m0, m1, lane);
+        // identical in every lane by construction; readfirstlane moves them to scalar registers
+        return box_of_extents(g, __builtin_amdgcn_readfirstlane(e.hmin), __builtin_amdgcn_readfirstlane(e.hmax),
+                              __builtin_amdgcn_readfirstlane(e.vmin), __builtin_amdgcn_readfirstlane(e.vmax), box_floats, prefer_stride);
+    }
+
+    // The boxes of up to 16 projections at once (fused kernel): lanes 4i .. 4i + 3 evaluate the four corner rays of projection
+    // first + i, lane 4i writes that box to tab[first + i] (BOX_WORDS words each). The per-projection cost of the box then is one
+    // LDS read and nine v_readlane instead of the whole evaluation repeated by every lane for every projection.
+    constexpr int BOX_WORDS = 12;
+
+    __device__ __forceinline__ void tile_boxes_to_lds(const BpParams& g, const float* sin_tab, const float* cos_tab, uint32_t first,
+                                                      uint32_t n_proj, uint32_t k0, uint32_t k1, uint32_t l0, uint32_t l1, uint32_t m0,
+                                                      uint32_t m1, uint32_t lane, uint32_t box_floats, int prefer_stride, int* tab)
+    {
+        // sin_tab / cos_tab are kernel arguments: indexed uniformly and handed to the owning lanes by a select
+        float sin_phi = 0.f, cos_phi = 1.f;
+#pragma unroll
+        for(uint32_t i = 0; i < 16u; ++i)
+        {
+            const uint32_t p = min(first + i, n_proj - 1u);
+            const bool mine = (lane >> 2) == i;
+            sin_phi = mine ? sin_tab[p] : sin_phi;
+            cos_phi = mine ? cos_tab[p] : cos_phi;
+        }
+        const BoxExtents e = tile_box_extents(g, sin_phi, cos_phi, k0, k1, l0, l1, m0, m1, lane);
+        const Box b = box_of_extents(g, e.hmin, e.hmax, e.vmin, e.vmax, box_floats, prefer_stride);
+        const uint32_t p = first + (lane >> 2);
+        if((lane & 3u) == 0u && p < n_proj)
+        {
+            int* w = tab + p * BOX_WORDS;
+            w[0] = b.bx0;
+            w[1] = b.by0;
+            w[2] = b.bw;
+            w[3] = b.bhs;
+            w[4] = b.stride;
+            w[5] = __float_as_int(b.row_lo);
+            w[6] = __float_as_int(b.row_hi);
+            w[7] = __float_as_int(b.first_row);
+            w[8] = __float_as_int(b.end_row);
+        }
+    }
+
+    // box p of the table, into scalar registers: lanes 0 .. 8 read one word each, nine v_readlane spread them
+    __device__ __forceinline__ Box box_from_lds(const int* tab, uint32_t p, uint32_t lane)
+    {
+        const int w = tab[p * BOX_WORDS + min(lane, static_cast<uint32_t>(BOX_WORDS - 1))];
+        Box b;
+        b.bx0 = __builtin_amdgcn_readlane(w, 0);
+        b.by0 = __builtin_amdgcn_readlane(w, 1);
+        b.bw = __builtin_amdgcn_readlane(w, 2);
+        b.bhs = __builtin_amdgcn_readlane(w, 3);
+        b.stride = __builtin_amdgcn_readlane(w, 4);
+        b.row_lo = __int_as_float(__builtin_amdgcn_readlane(w, 5));
+        b.row_hi = __int_as_float(__builtin_amdgcn_readlane(w, 6));
+        b.first_row = __int_as_float(__builtin_amdgcn_readlane(w, 7));
+        b.end_row = __int_as_float(__builtin_amdgcn_readlane(w, 8));
         return b;
     }
 
