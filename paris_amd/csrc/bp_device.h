@@ -273,6 +273,9 @@ namespace
         int bw;       // staged columns (0: nothing staged)
         int bhs;      // staged rows
         int stride;   // LDS row stride in floats (odd)
+        // 4-pixel staging of rows of at most 64 groups: rows one wave-instruction covers (64 / groups) and the multiplier that turns
+        // lane / groups into a multiply and a shift (ceil(2^16 / groups): exact for lane < 64); 0 for wider rows
+        int rpp, magic;
         // row bounds of the box as floats for make_column's tests (workgroup-uniform): a column's valid taps are inside the box iff
         // v_min >= row_lo and v_max < row_hi, where the bound is infinite on a side on which the box reaches the detector's edge
         float row_lo, row_hi;
@@ -380,6 +383,9 @@ namespace
         b.end_row = static_cast<float>(b.by0 + b.bhs - 1);
         b.row_lo = b.by0 == 0 ? -INFINITY : b.first_row;
         b.row_hi = (b.by0 + b.bhs >= static_cast<int>(g.p_dim_y)) ? INFINITY : b.end_row;
+        const int n4 = b.bw >> 2;
+        b.rpp = (n4 >= 1 && n4 <= 64) ? 64 / n4 : 0;
+        b.magic = (n4 >= 1 && n4 <= 64) ? (65536 + n4 - 1) / n4 : 0;
         return b;
     }
 
@@ -426,6 +432,8 @@ namespace
             w[6] = __float_as_int(b.row_hi);
             w[7] = __float_as_int(b.first_row);
             w[8] = __float_as_int(b.end_row);
+            w[9] = b.rpp;
+            w[10] = b.magic;
         }
     }
 
@@ -443,6 +451,8 @@ namespace
         b.row_hi = __int_as_float(__builtin_amdgcn_readlane(w, 6));
         b.first_row = __int_as_float(__builtin_amdgcn_readlane(w, 7));
         b.end_row = __int_as_float(__builtin_amdgcn_readlane(w, 8));
+        b.rpp = __builtin_amdgcn_readlane(w, 9);
+        b.magic = __builtin_amdgcn_readlane(w, 10);
         return b;
     }
 
@@ -464,11 +474,34 @@ namespace
             const uint32_t n4 = static_cast<uint32_t>(b.bw) >> 2; // groups of 4 per row
             if(n4 == 0u)
                 return;
-            const uint32_t rows_per_pass = n4 <= 64u ? 64u / n4 : 1u; // rows one wave-instruction covers
-            const uint32_t lr = n4 <= 64u ? lane / n4 : 0u;
+            const uint32_t rows_per_pass = n4 <= 64u ? static_cast<uint32_t>(b.rpp) : 1u; // rows one wave-instruction covers
+            const uint32_t lr = n4 <= 64u ? (lane * static_cast<uint32_t>(b.magic)) >> 16 : 0u; // lane / n4
             const uint32_t lc = n4 <= 64u ? lane - lr * n4 : lane;
             if(lr >= rows_per_pass)
                 return; // lanes beyond the last whole row of the pass idle
+            if(n4 <= 64u && !g.proj_f16)
+            {
+                // one group per lane and row: both addresses advance by a uniform step, two rows in flight per lane
+                const uint32_t step = n_waves * rows_per_pass;
+                uint32_t r = wave * rows_per_pass + lr;
+                const float* src = static_cast<const float*>(g.proj) + (static_cast<size_t>(b.by0) + r) * g.p_pitch + static_cast<size_t>(b.bx0) + 4u * lc;
+                float* dst = lds_box + r * static_cast<uint32_t>(b.stride) + 4u * lc;
+                const size_t src_step = static_cast<size_t>(step) * g.p_pitch;
+                const uint32_t dst_step = step * static_cast<uint32_t>(b.stride);
+                const uint32_t rows = static_cast<uint32_t>(b.bhs);
+                for(; r + step < rows; r += 2u * step)
+                {
+                    const float4 v0 = *reinterpret_cast<const float4*>(src);
+                    const float4 v1 = *reinterpret_cast<const float4*>(src + src_step);
+                    *reinterpret_cast<float4*>(dst) = v0;
+                    *reinterpret_cast<float4*>(dst + dst_step) = v1;
+                    src += 2u * src_step;
+                    dst += 2u * dst_step;
+                }
+                if(r < rows)
+                    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+                return;
+            }
             for(uint32_t r = wave * rows_per_pass + lr; r < static_cast<uint32_t>(b.bhs); r += n_waves * rows_per_pass)
             {
                 const size_t row = static_cast<size_t>(b.by0 + static_cast<int>(r)) * g.p_pitch + static_cast<size_t>(b.bx0);
