@@ -99,33 +99,29 @@ namespace
                     constexpr bool FULL = decltype(full_tag)::value; // whole tile: no per-slice test, one straight block
                     constexpr bool INSIDE = decltype(inside_tag)::value; // every tap valid: no validity test, clamp or select
                     constexpr int CS = decltype(stride_tag)::value;      // the box has the compile-time row stride
-                    if constexpr(FAST && FULL && PARIS_FUSED_PIPELINE)
+                    if constexpr(FAST && FULL && PARIS_FUSED_PIPELINE > 0)
                     {
-                        // two-stage pipeline over the slices: the LDS reads of slice z + 1 are in flight while slice z is finished
-                        Tap cur[VX];
+                        // software pipeline over the slices: the LDS reads of the next PARIS_FUSED_PIPELINE slices are in flight while
+                        // slice z is finished
+                        constexpr int AHEAD = PARIS_FUSED_PIPELINE;
+                        Tap ring[AHEAD + 1][VX];
+                        auto fetch = [&](int z) {
+                            const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + static_cast<uint32_t>(z)) * g.l_vx_z; // :118
 #pragma unroll
-                        for(int j = 0; j < VX; ++j)
-                            cur[j] = fetch_tap<FD, INSIDE, CS>(g, box, lds, g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z, col[j]);
+                            for(int j = 0; j < VX; ++j)
+                                ring[z % (AHEAD + 1)][j] = fetch_tap<FD, INSIDE, CS>(g, box, lds, z_m, col[j]);
+                        };
+#pragma unroll
+                        for(int z = 0; z < AHEAD && z < TZ; ++z)
+                            fetch(z);
 #pragma unroll
                         for(int z = 0; z < TZ; ++z)
                         {
-                            Tap next[VX];
-                            if(z + 1 < TZ)
-                            {
-                                const float z_n = g.z_base + static_cast<float>(g.m_off + m0 + z + 1) * g.l_vx_z; // :118
-#pragma unroll
-                                for(int j = 0; j < VX; ++j)
-                                    next[j] = fetch_tap<FD, INSIDE, CS>(g, box, lds, z_n, col[j]);
-                            }
+                            if(z + AHEAD < TZ)
+                                fetch(z + AHEAD);
 #pragma unroll
                             for(int j = 0; j < VX; ++j)
-                                elem<VX>(acc[z], j) += finish_tap<INSIDE>(col[j], cur[j]);
-                            if(z + 1 < TZ)
-                            {
-#pragma unroll
-                                for(int j = 0; j < VX; ++j)
-                                    cur[j] = next[j];
-                            }
+                                elem<VX>(acc[z], j) += finish_tap<INSIDE>(col[j], ring[z % (AHEAD + 1)][j]);
                         }
                         return;
                     }

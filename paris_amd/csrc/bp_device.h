@@ -479,16 +479,35 @@ namespace
             const uint32_t lc = n4 <= 64u ? lane - lr * n4 : lane;
             if(lr >= rows_per_pass)
                 return; // lanes beyond the last whole row of the pass idle
-            if(n4 <= 64u && !g.proj_f16)
+            if(n4 <= 64u)
             {
                 // one group per lane and row: both addresses advance by a uniform step, two rows in flight per lane
                 const uint32_t step = n_waves * rows_per_pass;
                 uint32_t r = wave * rows_per_pass + lr;
-                const float* src = static_cast<const float*>(g.proj) + (static_cast<size_t>(b.by0) + r) * g.p_pitch + static_cast<size_t>(b.bx0) + 4u * lc;
+                const size_t first = (static_cast<size_t>(b.by0) + r) * g.p_pitch + static_cast<size_t>(b.bx0) + 4u * lc;
                 float* dst = lds_box + r * static_cast<uint32_t>(b.stride) + 4u * lc;
                 const size_t src_step = static_cast<size_t>(step) * g.p_pitch;
                 const uint32_t dst_step = step * static_cast<uint32_t>(b.stride);
                 const uint32_t rows = static_cast<uint32_t>(b.bhs);
+                if(g.proj_f16)
+                {
+                    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                    auto widen = [](half4 h) { return make_float4(static_cast<float>(h.x), static_cast<float>(h.y), static_cast<float>(h.z), static_cast<float>(h.w)); };
+                    const _Float16* src = static_cast<const _Float16*>(g.proj) + first;
+                    for(; r + step < rows; r += 2u * step)
+                    {
+                        const half4 h0 = *reinterpret_cast<const half4*>(src);
+                        const half4 h1 = *reinterpret_cast<const half4*>(src + src_step);
+                        *reinterpret_cast<float4*>(dst) = widen(h0);
+                        *reinterpret_cast<float4*>(dst + dst_step) = widen(h1);
+                        src += 2u * src_step;
+                        dst += 2u * dst_step;
+                    }
+                    if(r < rows)
+                        *reinterpret_cast<float4*>(dst) = widen(*reinterpret_cast<const half4*>(src));
+                    return;
+                }
+                const float* src = static_cast<const float*>(g.proj) + first;
                 for(; r + step < rows; r += 2u * step)
                 {
                     const float4 v0 = *reinterpret_cast<const float4*>(src);
