@@ -692,7 +692,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         fp.cos_phi[0] = cos_phi;
         const int width = lane_width(d_v, v_dim_x);
         const int vx = ctx->bp_vx == 4 && width == 4 ? 4 : (ctx->bp_vx == 1 || width < 2 ? 1 : 2);
-        paris_hip_bp_launch_fused(&fp, vx, ctx->bp_tz == 8u ? 8 : 16, volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) != 0, fd, ctx->stream);
+        paris_hip_bp_launch_fused(&fp, vx, ctx->bp_tz == 8u ? 8 : (ctx->bp_tz == 32u ? 32 : 16), volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) != 0, fd, ctx->stream);
     }
     else
     if(ctx->bp_variant == 1)
@@ -975,15 +975,26 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
 
     // The cross-check variants take the sequence of single-projection launches that the fused kernel is defined to
     // equal, and so does a single projection: that is the tile kernel's case (memory bound, nothing to fuse).
-    // Lane width of the fused kernel: 2 voxels along x (16 slices x 2 accumulators leave room for five waves per SIMD,
-    // which its latency-bound loop needs: 1.30 TVox/s against 1.16 with 4 voxels per lane at three waves), 1 voxel for
-    // volumes whose rows are not 8-byte aligned; the tuning knob can ask for 4 or 1.
+    // Shape of the fused kernel. Default: one voxel per lane along x, 32 slices deep -- a column's per-projection setup (its two
+    // divisions, the detector column and weights, the tests that let its taps skip the per-voxel checks) is paid once per 32
+    // voxel-updates: +5 % over two columns x 16 slices on the 2048^3 grid, +9 % at 1024^3 (profiles/r02_tune_fused_shapes.txt);
+    // volumes of at most 16 slices keep the 16-slice tile. The tuning knob can ask for 2 or 4 voxels per lane (rows 8- / 16-byte
+    // aligned) and for 8, 16 or 32 slices (32 only with one voxel per lane, 8 only with 2 or 4).
     const int width = d_v != nullptr ? lane_width(d_v, v_dim_x) : 1;
-    int fused_vx = width >= 2 ? 2 : 1;
+    int fused_vx = (v_dim_z <= 16u && width >= 2) ? 2 : 1;
     if(ctx->bp_vx == 4 && width == 4)
         fused_vx = 4;
+    else if(ctx->bp_vx == 2 && width >= 2)
+        fused_vx = 2;
     else if(ctx->bp_vx == 1)
         fused_vx = 1;
+    int fused_tz = fused_vx == 1 ? (v_dim_z <= 16u ? 16 : 32) : 16;
+    if(ctx->bp_tz == 8u && fused_vx != 1)
+        fused_tz = 8;
+    else if(ctx->bp_tz == 16u)
+        fused_tz = 16;
+    else if(ctx->bp_tz == 32u && fused_vx == 1)
+        fused_tz = 32;
     const bool fused_ok = n_proj > 1 && (ctx->bp_variant == 0 || ctx->bp_variant == 4) && d_v != nullptr;
     if(!fused_ok)
     {
@@ -1003,7 +1014,6 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
     }
 
     const bool nt = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) != 0;
-    const bool tz16 = ctx->bp_tz != 8u; // 16 slices per tile unless 8 is asked for (tools/tune_bp.py --fused)
     for(uint32_t first = 0; first < n_proj; first += FUSED_MAX)
     {
         const uint32_t n = std::min<uint32_t>(FUSED_MAX, n_proj - first);
@@ -1031,7 +1041,7 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         const size_t ev = timed ? static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size()) : 0u;
         if(timed)
             PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
-        paris_hip_bp_launch_fused(&fp, fused_vx, (fused_vx == 1 && ctx->bp_tz == 32u) ? 32 : (tz16 ? 16 : 8), nt, fd, ctx->stream);
+        paris_hip_bp_launch_fused(&fp, fused_vx, fused_tz, nt, fd, ctx->stream);
         if(timed)
             PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
         ++ctx->bp_launches;

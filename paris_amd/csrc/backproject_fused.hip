@@ -81,6 +81,9 @@ namespace
             g.proj = base + static_cast<size_t>(p) * fp.proj_stride * px;
             __syncthreads(); // the previous projection's taps are done with the LDS box (p == 0: the table of boxes is written)
             const Box box = box_from_lds(box_tab, p, lane);
+#ifdef PARIS_TIMING_ONLY_STAGE_ONCE // wrong results: prices the per-projection staging (tools/README.md)
+            if(p == 0u)
+#endif
             stage_box(g, box, lds, wave, 4u, lane);
             __syncthreads();
             if(active)

@@ -856,12 +856,14 @@ def test_make_subvolume_information(be):
 
 @pytest.mark.parametrize("n_proj,tz,lds_bytes,vx,x2", [(9, 0, 0, 0, 82), (40, 0, 0, 0, 82), (9, 8, 0, 0, 82), (5, 0, 1024, 0, 82),
                                                          (33, 8, 4096, 0, 82), (9, 0, 0, 4, 82), (9, 8, 0, 4, 82), (9, 0, 0, 1, 82),
-                                                         (9, 0, 0, 0, 81), (7, 0, 1024, 0, 79), (9, 0, 0, 0, 80)])
+                                                         (9, 0, 0, 0, 81), (7, 0, 1024, 0, 79), (9, 0, 0, 0, 80),
+                                                         (9, 0, 0, 2, 82), (9, 8, 0, 2, 82), (33, 16, 2048, 2, 80), (9, 16, 0, 1, 82),
+                                                         (9, 32, 0, 1, 81), (5, 16, 1024, 0, 82)])
 def test_backproject_fused_batch_bit_exact(be, oracle, n_proj, tz, lds_bytes, vx, x2):
     """paris_hip_backproject_batch's fused kernel (n_proj projections per launch, split at 32) adds the projections
     to every voxel in projection order: bit-identical to the oracle's sequential loop. Partial tiles in x, y, z;
-    ROI and slab offset; both tile depths; an LDS budget that forces the global tap path; every lane width (default 2
-    voxels, 4 and 1 on request; odd-width volumes -- x2 = 81, 79 -- take 1, a 70-wide one 2)."""
+    ROI and slab offset; every tile depth (8, 16, 32); an LDS budget that forces the global tap path; every lane width (default:
+    one voxel per lane, 32 slices; 2 and 4 voxels on request where the rows are aligned for them)."""
     g = (96, 80, 0.2, 0.25, -2.5, 1.25, 150, 250, 9.0)
     det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
     nat = B.calculate_volume_geometry(det)
