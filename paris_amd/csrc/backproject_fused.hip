@@ -109,6 +109,8 @@ namespace
                         constexpr int AHEAD = PARIS_FUSED_PIPELINE;
                         Tap ring[AHEAD + 1][VX];
                         auto fetch = [&](int z) {
+                            // (the TZ slice coordinates stay in registers: reading them back from LDS per slice to make room for a deeper
+                            // pipeline cost 5 %, profiles/r02_ab_fused_steps.txt)
                             const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + static_cast<uint32_t>(z)) * g.l_vx_z; // :118
 #pragma unroll
                             for(int j = 0; j < VX; ++j)
