@@ -79,12 +79,18 @@ namespace
             g.sin_phi = fp.sin_phi[p];
             g.cos_phi = fp.cos_phi[p];
             g.proj = base + static_cast<size_t>(p) * fp.proj_stride * px;
+#ifdef PARIS_TIMING_ONLY_NO_BARRIERS // wrong results: prices the two barriers per projection
+            if(p == 0u)
+#endif
             __syncthreads(); // the previous projection's taps are done with the LDS box (p == 0: the table of boxes is written)
             const Box box = box_from_lds(box_tab, p, lane);
 #ifdef PARIS_TIMING_ONLY_STAGE_ONCE // wrong results: prices the per-projection staging (tools/README.md)
             if(p == 0u)
 #endif
             stage_box(g, box, lds, wave, 4u, lane);
+#ifdef PARIS_TIMING_ONLY_NO_BARRIERS
+            if(p == 0u)
+#endif
             __syncthreads();
             if(active)
             {

@@ -1,0 +1,42 @@
+#!/bin/bash
+# Regenerates the measured evidence of a round on the GPU box, into gpurun_out/final/ (copy what is to be judged into profiles/):
+#   bench lines of every single-GPU workload, rocprofv3 kernel statistics of the default bench command, HBM traffic (FETCH_SIZE and
+#   WRITE_SIZE in separate passes), SQ instruction / LDS counters and the wave-state counters of the backprojection kernels.
+# Run through gpurun from the repository root:  gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02'
+set -e
+tag=${1:-rNN}
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+out=gpurun_out/final
+rm -rf $out && mkdir -p $out
+export TMPDIR=/tmp
+run() { echo "== $*" >&2; "$@"; }
+# 1. counters first: bench.py's roofline.traffic and fused_extension.roofline read the newest records under profiles/
+#    (one --pmc pass each, nothing else traced); kernel times for the derived figures come from an unprofiled run
+run python bench.py --steps 8 --warmup 2 --cpu-budget 0 > $out/quick.json
+A="--steps 1 --warmup 1 --batch 2 --cpu-budget 0"
+run rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/prof_fetch -- python3 bench.py $A > /dev/null
+run rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/prof_write -- python3 bench.py $A > /dev/null
+python tools/pmc_traffic.py $out/prof_fetch $out/prof_write "2048^3 volume, 2048x2048 projections" $out/${tag}_pmc_traffic_c3.json
+echo "traffic done" >&2
+S="--steps 1 --warmup 1 --batch 8 --cpu-budget 0 --fused-steps 1"
+run rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $out/pmc_sq_a -- python3 bench.py $S > /dev/null
+run rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_sq_b -- python3 bench.py $S > /dev/null
+python tools/pmc_sq.py $out/pmc_sq_a $out/pmc_sq_b $out/quick.json $out/${tag}_pmc_sq_counters_c3.json "$S"
+run rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_w1 -- python3 bench.py $S > /dev/null
+python tools/pmc_wait.py $out/pmc_w1 $out/pmc_sq_a > $out/${tag}_pmc_wave_states_c3.json
+cp $out/${tag}_pmc_traffic_c3.json $out/${tag}_pmc_sq_counters_c3.json profiles/
+echo "counters done" >&2
+# 2. the bench lines
+run python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_c3.json
+run python bench.py --steps 20 --warmup 5 --workload c3 --slices 256 --cpu-budget 0 > $out/${tag}_bench_c4_slab_shape_1gpu.json
+run python bench.py --steps 20 --warmup 5 --workload c2 --cpu-budget 0 > $out/${tag}_bench_c2_1gpu.json
+run python bench.py --steps 20 --warmup 5 --workload c1 --cpu-budget 0 > $out/${tag}_bench_c1_1gpu.json
+run python bench.py --steps 20 --warmup 5 --workload c1 --graph 1 --cpu-budget 0 > $out/${tag}_bench_c1_graph_1gpu.json
+run python bench.py --steps 20 --warmup 5 --workload c5 --cpu-budget 0 > $out/${tag}_bench_c5_1gpu.json
+echo "benches done" >&2
+# 3. the same default command under the profiler (kernel trace only)
+run rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 5 --cpu-budget 0 > $out/${tag}_bench_under_rocprof_c3.json
+cp $(ls $out/stats/*/*_kernel_stats.csv | head -1) $out/${tag}_kernel_stats_bench_c3_whole_job.csv
+echo "kernel stats done" >&2
+rm -rf $out/stats $out/prof_fetch $out/prof_write $out/pmc_sq_a $out/pmc_sq_b $out/pmc_w1 $out/quick.json
+ls -la $out >&2

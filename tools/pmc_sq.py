@@ -38,7 +38,7 @@ def main():
            + "  (two passes; values are device-wide sums per launch, averaged over the launches seen)", "kernels": {}}
     for key, label, ms, updates in (
             ("bp_tile", "bp_tile_kernel (1 projection per launch)", bench["config"]["backproject_kernel_ms"], voxels),
-            ("bp_fused", "bp_fused_kernel<2,16> (%d projections per launch)" % fb, bench["fused_extension"]["kernel_ms_per_launch"], voxels * fb)):
+            ("bp_fused", "bp_fused_kernel, default shape (%d projections per launch)" % fb, bench["fused_extension"]["kernel_ms_per_launch"], voxels * fb)):
         c = {}
         for src in (a, b):
             for name, vals in src.get(key, {}).items():

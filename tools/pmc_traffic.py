@@ -28,10 +28,10 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
-def values(d, counter):
+def values(d, counter, kernel="bp_tile"):
     f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
     return [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if "bp_tile" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
 
 
 def main():
@@ -43,6 +43,13 @@ def main():
            "traffic_bytes_per_launch": sum(l["hbm_bytes"] for l in launches) / len(launches),
            "kernel_source_sha16": kernel_source_sha16(),
            "note": "FETCH_SIZE x 1024 x 2 (gfx950 half-count of wide streaming reads) + WRITE_SIZE x 1024"}
+    # the fused kernel's launches of the same runs (bench.py's fused_extension steps), when there are any: volume read and written
+    # once per launch + whatever of the projections' box staging misses the L2
+    ff, fw = values(fetch_dir, "FETCH_SIZE", "bp_fused"), values(write_dir, "WRITE_SIZE", "bp_fused")
+    if ff and fw:
+        out["fused_kernel"] = {"launches": len(ff), "fetch_bytes_corrected_per_launch": sum(ff) / len(ff) * 2048,
+                               "write_bytes_per_launch": sum(fw) / len(fw) * 1024,
+                               "traffic_bytes_per_launch": sum(ff) / len(ff) * 2048 + sum(fw) / len(fw) * 1024}
     json.dump(out, open(out_path, "w"), indent=1)
     print(out["traffic_bytes_per_launch"])
 
