@@ -16,7 +16,7 @@ run python bench.py --steps 8 --warmup 2 --cpu-budget 0 > $out/quick.json
 A="--steps 1 --warmup 1 --batch 2 --cpu-budget 0"
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/prof_fetch -- python3 bench.py $A > /dev/null
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/prof_write -- python3 bench.py $A > /dev/null
-python tools/pmc_traffic.py $out/prof_fetch $out/prof_write "2048^3 volume, 2048x2048 projections" $out/${tag}_pmc_traffic_c3.json
+python tools/pmc_traffic.py $out/prof_fetch $out/prof_write "2048^3 volume, 1440 projections @ 2048x2048 fp32" $out/${tag}_pmc_traffic_c3.json
 echo "traffic done" >&2
 S="--steps 1 --warmup 1 --batch 8 --cpu-budget 0 --fused-steps 1"
 run rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $out/pmc_sq_a -- python3 bench.py $S > /dev/null
