@@ -579,7 +579,8 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     // grows as 1 / depth and the detector rows an XCD reads grow with the depth it sweeps. Planes beyond 1024^2: order 12 (order 8
     // in chunks of 256 slices, so the detector band of a chunk stays in the XCD's L2) -- with 8-slice tiles for slabs up to 512
     // slices (2048 x 2048 x 256: 1.447 against 1.491 ms inside bench.py's step, +3 %), with 16-slice tiles for deeper volumes
-    // (2048^3: +0.2 %; 8-slice tiles are +1.1 % on one device and -0.4 % on another there). Planes up to 1024^2: order 5 with 8-slice
+    // (2048^3: +0.2 %; 8-slice tiles are +1.1 % on one device and -0.4 % on another there; measured again after the tile prologue
+    // lost its integer divisions: +0.65 % on one device, -1.2 % on the next, profiles/r02_ab_tile_depth_full_volume.txt). Planes up to 1024^2: order 5 with 8-slice
     // tiles (+2.5 %; the band orders lose 3 %), up to 512^2 with 16-slice tiles.
     const uint64_t plane = static_cast<uint64_t>(v_dim_x) * v_dim_y;
     const uint32_t tz_auto = plane > (1ull << 20) ? (v_dim_z <= 512u ? 8u : TZ_DEFAULT) : (plane > (1ull << 18) ? 8u : TZ_DEFAULT);
