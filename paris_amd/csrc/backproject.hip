@@ -982,14 +982,26 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
     // volumes of at most 16 slices keep the 16-slice tile. The tuning knob can ask for 2 or 4 voxels per lane (rows 8- / 16-byte
     // aligned) and for 8, 16 or 32 slices (32 only with one voxel per lane, 8 only with 2 or 4).
     const int width = d_v != nullptr ? lane_width(d_v, v_dim_x) : 1;
-    int fused_vx = (v_dim_z <= 16u && width >= 2) ? 2 : 1;
+    // ... provided the detector box of a 64 x 4 x 32 tile fits the LDS budget at this geometry's magnification (coarse grids on
+    // fine detectors do not: 256^3 from 512^2 projections needs 76 rows of 144 floats for 32 slices, most taps would take the
+    // global path and 2 x 16 is 24 % faster there, profiles/r02_ab_fused_steps.txt)
+    bool deep_box_fits = true;
+    {
+        const double d_so = std::fabs(static_cast<double>(det_geo->d_so)), d_sd = d_so + std::fabs(static_cast<double>(det_geo->d_od));
+        const double mag = d_so > 0.0 ? d_sd / d_so : 1.0; // at the rotation axis: most tiles are near it
+        const double rows = 32.0 * vol_geo->l_vx_z * mag / det_geo->l_px_col + 4.0 * std::max(vol_geo->l_vx_x, vol_geo->l_vx_y) * mag / det_geo->l_px_col + 8.0;
+        const double cols = 64.0 * std::max(vol_geo->l_vx_x, vol_geo->l_vx_y) * mag / det_geo->l_px_row + 16.0;
+        const double budget = ctx->bp_lds_bytes != 0u ? ctx->bp_lds_bytes : 32.0 * 1024.0;
+        deep_box_fits = std::isfinite(rows) && std::isfinite(cols) && rows * std::max(132.0, cols) * sizeof(float) <= budget;
+    }
+    int fused_vx = ((v_dim_z <= 16u || !deep_box_fits) && width >= 2) ? 2 : 1;
     if(ctx->bp_vx == 4 && width == 4)
         fused_vx = 4;
     else if(ctx->bp_vx == 2 && width >= 2)
         fused_vx = 2;
     else if(ctx->bp_vx == 1)
         fused_vx = 1;
-    int fused_tz = fused_vx == 1 ? (v_dim_z <= 16u ? 16 : 32) : 16;
+    int fused_tz = fused_vx == 1 ? ((v_dim_z <= 16u || !deep_box_fits) ? 16 : 32) : 16;
     if(ctx->bp_tz == 8u && fused_vx != 1)
         fused_tz = 8;
     else if(ctx->bp_tz == 16u)
