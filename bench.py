@@ -322,8 +322,15 @@ def main():
     nb = max(16, fb)  # work slots and distinct raw frames; a step cycles through them (stream order makes the reuse safe)
     raw = torch.rand((nb, n_col, n_row), generator=gen, device=dev, dtype=torch.float32)
     work = torch.empty_like(raw)
-    vol = torch.zeros((z_count, out_geo.dim_y, out_geo.dim_x), device=dev, dtype=torch.float32)
-    d_vol = be.wrap_volume(vol.data_ptr(), out_geo.dim_x, out_geo.dim_y, z_count, owner=vol)
+    # the slab comes from the library's make_volume_device, as PARIS's does (src/make_volume.cpp:36): zero-filled, and known to the
+    # library as a volume nothing but backprojections writes (paris_hip_set_backproject_skip_invalid); torch sees the same memory
+    d_vol = be.make_volume_device(out_geo.dim_x, out_geo.dim_y, z_count)
+
+    class _DeviceMemory:
+        def __init__(self, ptr, shape):
+            self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+    vol = torch.as_tensor(_DeviceMemory(d_vol.ptr, (z_count, out_geo.dim_y, out_geo.dim_x)), device=dev)
     f16 = bool(w.get("f16"))
     half = torch.empty((n_col, n_row), device=dev, dtype=torch.float16) if f16 else None
     pitch = work.stride(1) * 4

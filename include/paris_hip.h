@@ -198,6 +198,15 @@ int paris_hip_set_filter_variant(paris_hip_ctx* ctx, int variant);
  * on by paris::hip (C++ mirror) and bench.py. Ignored under PARIS_HIP_CTX_SYNCHRONOUS. */
 int paris_hip_set_stage_fusion(paris_hip_ctx* ctx, int enable);
 
+/* Extension: tiles no ray reaches. Where none of a projection's rays reaches any voxel column of a wave's tile -- the corners of
+ * the grid outside the field of view, slices above / below the cone on the source side: about a tenth of a 2048^3 launch at the
+ * natural grid -- the reference adds 0.5 * 0 * u * u = +0 to every voxel (src/openmp/backprojection.cpp:71,140). Adding +0 changes
+ * a float only if it is -0, and a volume that paris_hip_malloc_volume allocated (zero-filled) and that nothing but backprojections
+ * wrote since cannot hold one (a sum is -0 only if both terms are). For such volumes, with enable != 0 (the default), those waves
+ * neither load nor store their tile; the result is bit-identical. Volumes the library did not allocate, and volumes a
+ * paris_hip_memcpy_volume_h2d wrote into, always take every addition. */
+int paris_hip_set_backproject_skip_invalid(paris_hip_ctx* ctx, int enable);
+
 /* Extension: weighting and row filter of rows [row_first, row_first + row_count) in one launch, explicitly. d_half != NULL:
  * the filtered rows are stored as IEEE half (round to nearest even) into d_half (same row numbering, half_pitch bytes per
  * row) and the fp32 rows stay as they were (BASELINE config 5: saves the conversion pass). d_k must come from

@@ -219,6 +219,11 @@ class Backend:
     def set_filter_variant(self, variant):
         check(self._L.paris_hip_set_filter_variant(self._ctx, variant), "paris_hip_set_filter_variant")
 
+    def set_backproject_skip_invalid(self, enable=True):
+        """paris_hip_set_backproject_skip_invalid: tiles no ray of a projection reaches are left untouched (library-allocated
+        volumes only; default on)"""
+        check(self._L.paris_hip_set_backproject_skip_invalid(self._ctx, int(bool(enable))), "paris_hip_set_backproject_skip_invalid")
+
     def set_stage_fusion(self, enable=True):
         """weight() is held back and rides along in the load of the apply_filter() that follows (one launch)"""
         check(self._L.paris_hip_set_stage_fusion(self._ctx, int(bool(enable))), "paris_hip_set_stage_fusion")

@@ -118,7 +118,7 @@ namespace
         const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
         const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
         Column col[VX];
-        bool all_fast = true;
+        bool all_fast = true, all_none = true;
 #pragma unroll
         for(int j = 0; j < VX; ++j)
         {
@@ -133,11 +133,17 @@ namespace
             else
                 col[j] = make_column<FD>(g, box, g.k_off + min(k + j, k1), g.l_off + min(l, l1), z_first, z_last);
             all_fast = all_fast && col[j].fast;
+            all_none = all_none && col[j].none;
         }
 
         // (keeping the box loads in flight across this setup was measured slower: profiles/r01_ab_full_volume_6.jsonl)
         __syncthreads();
         if(!active)
+            return;
+        // no ray of this projection reaches any column of the wave (the corners of the grid outside the field of view, slices above /
+        // below the cone on the source side): every contribution is +0 and the volume holds no -0, so the tile is left as it is --
+        // about a tenth of a 2048^3 launch's traffic at the natural grid
+        if(g.skip_invalid != 0u && __all(all_none ? 1 : 0) != 0)
             return;
 
         using vec_t = typename vec_of<VX>::type;
@@ -295,10 +301,10 @@ namespace
                 const float4 y4 = *reinterpret_cast<const float4*>(c_ymax + c);
                 const int4 o4 = *reinterpret_cast<const int4*>(c_xoff + c);
                 const int4 i4 = *reinterpret_cast<const int4*>(c_x1i + c);
-                acc[r].x += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.x, u4.x, a4.x, b4.x, y4.x, o4.x, i4.x, FAST, false});
-                acc[r].y += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.y, u4.y, a4.y, b4.y, y4.y, o4.y, i4.y, FAST, false});
-                acc[r].z += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.z, u4.z, a4.z, b4.z, y4.z, o4.z, i4.z, FAST, false});
-                acc[r].w += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.w, u4.w, a4.w, b4.w, y4.w, o4.w, i4.w, FAST, false});
+                acc[r].x += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.x, u4.x, a4.x, b4.x, y4.x, o4.x, i4.x, FAST, false, false});
+                acc[r].y += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.y, u4.y, a4.y, b4.y, y4.y, o4.y, i4.y, FAST, false, false});
+                acc[r].z += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.z, u4.z, a4.z, b4.z, y4.z, o4.z, i4.z, FAST, false, false});
+                acc[r].w += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.w, u4.w, a4.w, b4.w, y4.w, o4.w, i4.w, FAST, false, false});
             }
         };
         if(all_fast)
@@ -643,6 +649,8 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     }
     g.p_dim_x_f = static_cast<float>(p_dim_x);
     g.p_dim_y_f = static_cast<float>(p_dim_y);
+    g.skip_invalid = (ctx->bp_skip_invalid != 0 && d_v != nullptr
+                      && paris_hip_volume_is_clean(ctx, d_v, static_cast<size_t>(v_dim_x) * v_dim_y * v_dim_z * sizeof(float))) ? 1u : 0u;
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
     g.tz = tz;
     // default mapping: see the tile depth above (a y band per XCD beyond 1024^2 planes, a contiguous run of tiles per XCD below)
@@ -1120,6 +1128,16 @@ extern "C" int paris_hip_set_backproject_vector_staging(paris_hip_ctx* ctx, int 
     if(ctx == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_stage_vec4 = enable ? 1 : 0;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_set_backproject_skip_invalid(paris_hip_ctx* ctx, int enable)
+{
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
+    if(ctx == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    ctx->bp_skip_invalid = enable ? 1 : 0;
     return PARIS_HIP_SUCCESS;
 }
 

@@ -47,6 +47,9 @@ namespace
         const float* colstate;  // two-pass variant: factor, h, u planes of v_dim_x * v_dim_y floats each (NULL: computed in the kernel)
         uint32_t store_sc1;     // nontemporal stores also carry sc1 (write-through)
         uint32_t stage_vec4;    // detector rows may be staged 4 pixels at a time (base and pitch aligned)
+        // The volume holds no -0 (zero-filled by the library and written by backprojections only since: a sum of floats is -0 only
+        // if both terms are): adding +0 then changes nothing, and waves whose columns all have Column::none skip the tile
+        uint32_t skip_invalid;
     };
 
     struct ColConst
@@ -572,6 +575,7 @@ namespace
         int x1i;        // detector column of the left tap (global-memory path)
         bool fast;      // every valid tap of this column, over the tile's whole z range, lies inside the staged box
         bool inside;    // stronger: EVERY tap of this column over the tile's z range is valid and inside the staged box
+        bool none;      // NO tap of this column over the tile's z range is valid and u is finite: every contribution is exactly +0
     };
 
     // z_first / z_last: centred z of the tile's first and last slice. The per-slice coordinate v is a monotone
@@ -628,6 +632,11 @@ namespace
         // for the integers by0, bhs; a NaN fails both comparisons. By the monotonicity argument above every slice in between is
         // inside too: such a column needs neither the per-voxel validity test nor the row clamp nor the final select.
         col.inside = x_valid && finite_factor && col.xoff >= 0 && b.bhs >= 2 && v_min >= b.first_row && v_max < b.end_row;
+        // No valid tap at all -- the column's x taps are off the detector, or (by the same monotonicity) its rows are above or below
+        // it over the whole tile: :71 then sets det = 0 and :140 adds 0.5 * 0 * u * u, which is +0 for every finite u. A wave of such
+        // columns has nothing to add (and, where the volume is known to hold no -0, nothing to load or store: BpParams::skip_invalid).
+        const bool finite_u = (c.u - c.u) == 0.f;
+        col.none = finite_u && (!x_valid || (ordered && ((v_max < 0.f) || (v_min >= g.p_dim_y_f - 1.f))));
         return col;
     }
 
@@ -776,6 +785,45 @@ namespace
         t.q21 = r1[1];
         t.q12 = r2[0];
         t.q22 = r2[1];
+        return t;
+    }
+
+    // The general tap (voxel_contribution<FD, false>'s first half): validity from the float coordinates (:65-68, a NaN coordinate is
+    // invalid), rows clamped into the staged box, and a valid tap outside the box read from the detector in global memory. `live`
+    // (workgroup-uniform): the slice exists; taps of slices beyond the volume's last one are invalid.
+    template <bool FD>
+    __device__ __forceinline__ Tap fetch_tap_general(const BpParams& g, const Box& b, const float* lds_box, float z_m, const Column& col, bool live)
+    {
+        Tap t;
+        const float v = v_coordinate<FD>(g, z_m, col.factor);
+        const float y1 = floorf(v);
+        const float y2 = y1 + 1.f;
+        const int y1i = static_cast<int>(y1);
+        t.wy1 = v - y1; // for a valid tap 1 - wy1 == y2 - v bit for bit (see voxel_contribution)
+        t.valid = live && (y1 >= 0.f) && (y2 < col.ymax); // :67-68 (+ x validity)
+        const int rrel = y1i - b.by0;
+        const int bhs_m2 = b.bhs - 2;
+        int rc;
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(rc) : "v"(rrel), "v"(max(bhs_m2, 0)));
+        using lds_cptr = const __attribute__((address_space(3))) float*;
+        const int stride4 = b.stride << 2;
+        const uint32_t xaddr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_box)) + (static_cast<uint32_t>(max(col.xoff, 0)) << 2);
+        const uint32_t a1 = static_cast<uint32_t>(__mul24(rc, stride4)) + xaddr;
+        lds_cptr r1 = reinterpret_cast<lds_cptr>(a1);
+        lds_cptr r2 = reinterpret_cast<lds_cptr>(a1 + static_cast<uint32_t>(stride4));
+        t.q11 = r1[0];
+        t.q21 = r1[1];
+        t.q12 = r2[0];
+        t.q22 = r2[1];
+        const bool inbox = col.xoff >= 0 && rrel >= 0 && rrel <= bhs_m2;
+        if(t.valid && !inbox)
+        {
+            const size_t at = static_cast<size_t>(y1i) * g.p_pitch + col.x1i;
+            t.q11 = read_pixel(g, at);
+            t.q21 = read_pixel(g, at + 1);
+            t.q12 = read_pixel(g, at + g.p_pitch);
+            t.q22 = read_pixel(g, at + g.p_pitch + 1);
+        }
         return t;
     }
 

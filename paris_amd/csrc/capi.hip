@@ -392,7 +392,7 @@ extern "C" int paris_hip_memset_volume(paris_hip_ctx* ctx, float* d_ptr, uint32_
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     const size_t bytes = static_cast<size_t>(dim_x) * dim_y * dim_z * sizeof(float);
     PARIS_HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, ctx->stream));
-    return paris_hip_finish(ctx);
+    return paris_hip_finish(ctx); // (zeros written into a listed volume leave it clean; one that was taken off the list stays off)
 }
 
 extern "C" int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, float** d_ptr)
@@ -412,7 +412,30 @@ extern "C" int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint3
         return static_cast<int>(err);
     }
     *d_ptr = static_cast<float*>(p);
+    ctx->clean_volumes[reinterpret_cast<uintptr_t>(p)] = bytes;
     return paris_hip_finish(ctx);
+}
+
+// [d_v, d_v + bytes) lies inside a volume this library allocated zero-filled and nothing but backprojections wrote since
+bool paris_hip_volume_is_clean(const paris_hip_ctx* ctx, const void* d_v, size_t bytes)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_v);
+    auto it = ctx->clean_volumes.upper_bound(a);
+    if(it == ctx->clean_volumes.begin())
+        return false;
+    --it;
+    return a >= it->first && a + bytes <= it->first + it->second;
+}
+
+namespace
+{
+    // a write from outside the backprojection kernels into [p, p + bytes): volumes it touches are no longer known to be free of -0
+    void volume_written(paris_hip_ctx* ctx, const void* p, size_t bytes)
+    {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        for(auto it = ctx->clean_volumes.begin(); it != ctx->clean_volumes.end();)
+            it = (a < it->first + it->second && it->first < a + bytes) ? ctx->clean_volumes.erase(it) : std::next(it);
+    }
 }
 
 extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
@@ -423,6 +446,7 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
         return PARIS_HIP_SUCCESS;
     if(int rc = paris_hip_flush_pending_weight(ctx))
         return rc;
+    ctx->clean_volumes.erase(reinterpret_cast<uintptr_t>(d_ptr));
     auto filt = ctx->filters.find(static_cast<const float*>(d_ptr));
     if(filt != ctx->filters.end())
     {
@@ -597,6 +621,7 @@ extern "C" int paris_hip_memcpy_volume_h2d(paris_hip_ctx* ctx, float* d_dst, con
     if(d_dst == nullptr || h_src == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     const size_t bytes = static_cast<size_t>(dim_x) * dim_y * dim_z * sizeof(float);
+    volume_written(ctx, d_dst, bytes); // the host's data may hold -0
     PARIS_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return paris_hip_finish(ctx);
 }

@@ -56,6 +56,11 @@ struct paris_hip_ctx
     int bp_nt = -1;    // volume stream policy: -1 automatic by slab size, 0 plain, 1 nontemporal, 2 nontemporal + write-through stores
     int bp_stage_vec4 = 1; // stage the detector box 4 pixels per lane when the projection's alignment allows
     int bp_fastdiv = 1; // use the validated multiply+2 FMA division by the pixel pitch when it is exact
+    int bp_skip_invalid = 1; // waves none of whose columns a projection's rays reach leave their tile untouched (clean volumes only)
+    // Volumes known to hold no -0: allocated (zero-filled) or zero-filled again by this library and written by nothing but
+    // backprojections since (base address -> bytes). A host upload into one removes it; memory the library did not allocate is
+    // never listed.
+    std::map<uintptr_t, size_t> clean_volumes;
     int bp_lean_div = 1; // share one reciprocal between the two per-column divisions by s + d_so when the operands are in range
     std::map<uint32_t, bool> fastdiv_exact; // divisor bits -> exhaustive check result
     bool filter_lds_attr_set = false;
@@ -183,6 +188,7 @@ int paris_hip_get_plan(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_plan** out)
 int paris_hip_flush_pending_weight(paris_hip_ctx* ctx);
 
 // filter_fused.hip
+bool paris_hip_volume_is_clean(const paris_hip_ctx* ctx, const void* d_v, size_t bytes); // capi.hip
 int paris_hip_fused_filter_tables(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_plan* plan);
 int paris_hip_fused_filter_permute_k(paris_hip_ctx* ctx, const float* d_k, uint32_t n, float** d_kp);
 int paris_hip_fused_filter_launch(paris_hip_ctx* ctx, float* d_rows, uint32_t pitch_f, uint32_t dim_x, uint32_t n_rows, uint32_t row_first,

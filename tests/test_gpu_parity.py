@@ -680,6 +680,61 @@ def test_backproject_shared_reciprocal_division_range(be, oracle, reach_over_d_s
     assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_backproject_tiles_no_ray_reaches(be, oracle, fused):
+    """A grid much wider and taller than the cone: for every projection most waves' tiles lie entirely outside the rays (x taps
+    off the detector, or rows above / below it over the tile's whole depth). On a volume the library allocated those waves skip
+    their tile (paris_hip_set_backproject_skip_invalid, default); with the switch off, and on a volume the host uploaded -- it may
+    hold -0, which the reference's + 0 turns into +0 -- every addition is made. All equal the oracle bit for bit, including the
+    sign of the zeros."""
+    g = (64, 48, 0.4, 0.4, 1.5, -2.0, 200, 150, 23.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    dims = (96, 72, 192)  # z, y, x: about three times the field of view across, twice its height
+    dz, dy, dx = dims
+    l_vx = float(nat.l_vx_x)
+    vg = B.VolumeGeometry(dx, dy, dz, l_vx * 1.1, l_vx * 2.6, l_vx * 1.7)
+    ovg = oracle.VolumeGeometry(dx, dy, dz, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    n = 9
+    projs = [oracle.lcg_projection(64, 48, i) - np.float32(0.5) for i in range(n)]
+    start = np.zeros(dims, np.float32)
+    start[::3, ::5, ::7] = np.float32(-0.0)  # the uploaded volume's -0 entries
+    want_zero = oracle_backproject_all(oracle, projs, odet, ovg, dims)
+    want_up = start.copy()
+    for i, p in enumerate(projs):
+        s, c, ds, dt = oracle.backproject_constants(odet, i)
+        oracle.backproject(want_up, p, 0, odet, ovg, s, c, ds, dt, None)
+    assert np.signbit(want_up[want_up == 0]).sum() == 0  # the reference's + 0 leaves no -0 behind
+
+    def run(d_v):
+        if fused:
+            rows, cols = 48, 64
+            stack = be.make_projection_device(cols, rows * n)
+            be.copy_h2d(B.Projection(np.ascontiguousarray(np.stack(projs).reshape(n * rows, cols)), cols, rows * n), stack)
+            sc = [B.stage_angle(det, i) for i in range(n)]
+            be.backproject_batch(stack.ptr, stack.pitch, stack.pitch * rows, n, cols, rows, d_v, 0, det, vg, False, None,
+                                 [s_ for s_, _ in sc], [c_ for _, c_ in sc], det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
+            be.free(stack)
+        else:
+            for i, p in enumerate(projs):
+                d_p = to_device(be, p, idx=i)
+                B.backproject(be, d_p, d_v, 0, det, vg, False, False, None)
+                be.free(d_p)
+        out = volume_to_host(be, d_v)
+        be.free(d_v)
+        return out
+
+    for skip in (True, False):
+        be.set_backproject_skip_invalid(skip)
+        try:
+            assert_bit_equal(run(be.make_volume_device(dx, dy, dz)), want_zero)
+            d_v = be.make_volume_device(dx, dy, dz)
+            be.copy_h2d(B.Volume(start.copy(), dx, dy, dz), d_v)
+            assert_bit_equal(run(d_v), want_up)
+        finally:
+            be.set_backproject_skip_invalid(True)
+
+
 def test_backproject_with_angle_file_values(be, oracle):
     """enable_angles: phi comes from projection::phi instead of idx * delta_phi (src/backprojection.cpp:52-57)."""
     det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
