@@ -19,12 +19,6 @@ namespace
 #ifndef PARIS_FUSED_PIPELINE
 #define PARIS_FUSED_PIPELINE 1
 #endif
-#ifndef PARIS_FUSED_PARTS
-#define PARIS_FUSED_PARTS 4
-#endif
-#ifndef PARIS_FUSED_THREE_MODES
-#define PARIS_FUSED_THREE_MODES 1
-#endif
 #ifndef PARIS_FUSED_WAVES
 #define PARIS_FUSED_WAVES 3
 #endif
@@ -67,13 +61,8 @@ namespace
         vec acc[TZ];
 #pragma unroll
         for(int z = 0; z < TZ; ++z)
-        {
-#pragma unroll
-            for(int j = 0; j < VX; ++j)
-                elem<VX>(acc[z], j) = 0.f; // lanes and slices beyond the volume: summed like the others, never stored
             if(active && static_cast<uint32_t>(z) < mcount)
                 acc[z] = load_voxels<VX, NT>(vp + z * slice);
-        }
 
         const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
         const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
@@ -103,125 +92,86 @@ namespace
             if(p == 0u)
 #endif
             __syncthreads();
-            // ONE code path adds a projection, and every lane takes it -- the lanes beyond the volume's edge with the columns of the
-            // last lane inside (their sums are never stored). With several paths (or a per-lane bypass) updating the TZ x VX sums the
-            // register allocator keeps an "in" and an "out" set of them, copies one onto the other at the end of every projection and
-            // spills around them: -8 % (timing-only build with the all-valid path alone, profiles/r02_ab_fused_steps.txt). What
-            // differs between interior tiles, boundary tiles and taps that left the staged box is confined to how a tap is FETCHED
-            // (wave-uniform `mode`, below); the sums see one addition per slice in one place.
+            if(active)
             {
                 Column col[VX];
                 bool all_fast = true, all_inside = true, all_none = true;
 #pragma unroll
                 for(int j = 0; j < VX; ++j)
                 {
-                    col[j] = make_column<FD>(g, box, g.k_off + min(k + static_cast<uint32_t>(j), k1), g.l_off + min(l, l1), z_first, z_last);
+                    col[j] = make_column<FD>(g, box, g.k_off + k + j, g.l_off + l, z_first, z_last);
                     all_fast = all_fast && col[j].fast;
                     all_inside = all_inside && col[j].inside;
                     all_none = all_none && col[j].none;
                 }
-                // 0: every tap of the wave valid and inside a box with the compile-time stride (interior tiles: most of the field of
-                //    view) -- no validity test, no clamp, both rows from one address register;
-                // 1: every lane's valid taps inside the box (boundary tiles, wide boxes, a last tile of fewer than TZ slices);
-                // 2: some tap may leave the box: per-tap check and the global-memory path;
-                // 3: no ray of this projection reaches any column of the wave: every contribution is +0, and the volume holds no -0
-                //    (BpParams::skip_invalid): nothing to add. About a tenth of the (wave, projection) pairs of a 2048^3 launch.
-                const bool wave_inside = mcount == TZ && g.p_dim_y < (1u << 23) && box.stride == FIXED_STRIDE && __all(all_inside ? 1 : 0) != 0;
-#ifdef PARIS_TIMING_ONLY_FORCE_MODE // wrong results: every wave through one mode's code
-                const int mode = (void(wave_inside), PARIS_TIMING_ONLY_FORCE_MODE);
-#else
-                const int mode = (g.skip_invalid != 0u && __all(all_none ? 1 : 0) != 0) ? 3 : wave_inside ? 0 : (__all(all_fast ? 1 : 0) != 0 ? 1 : 2);
-#endif
-                constexpr int AHEAD = PARIS_FUSED_PIPELINE > 0 ? PARIS_FUSED_PIPELINE : 1;
-                // The tile's slices in PARTS runs: each run's contributions are computed by the mode's own straight-line, software-
-                // pipelined code (the LDS reads of the next AHEAD slices in flight while a slice is finished) into temporaries, and
-                // added to the sums after the branches have joined -- the sums have ONE update site per run.
-                constexpr int PARTS = PARIS_FUSED_PARTS <= TZ / 4 ? PARIS_FUSED_PARTS : 1;
-                constexpr int ZN = TZ / PARTS;
-                auto z_of = [&](int z) { return g.z_base + static_cast<float>(g.m_off + m0 + static_cast<uint32_t>(z)) * g.l_vx_z; }; // :118
-                // (the TZ slice coordinates stay in registers: reading them back from LDS per slice to make room for a deeper pipeline
-                // cost 5 %, profiles/r02_ab_fused_steps.txt)
-                auto run = [&](auto part_tag) {
-                    constexpr int Z0 = decltype(part_tag)::value * ZN;
-                    float c[ZN][VX];
-                    auto contributions = [&](auto mode_tag) {
-                        constexpr int MODE = decltype(mode_tag)::value;
-                        if constexpr(MODE == 2)
-                        {
-                            // the rare general path: one slice after the other
-#pragma unroll
-                            for(int z = 0; z < ZN; ++z)
-#pragma unroll
-                                for(int j = 0; j < VX; ++j)
-                                {
-                                    c[z][j] = finish_tap<false>(col[j], fetch_tap_general<FD>(g, box, lds, z_of(Z0 + z), col[j], static_cast<uint32_t>(Z0 + z) < mcount));
-                                    asm volatile("" : "+v"(c[z][j])); // anchor: keeps the compiler from gathering all fetches first and holding every tap
-                                }
-                            return;
-                        }
+                auto add_projection = [&](auto fast_tag, auto full_tag, auto inside_tag, auto stride_tag) {
+                    constexpr bool FAST = decltype(fast_tag)::value;
+                    constexpr bool FULL = decltype(full_tag)::value; // whole tile: no per-slice test, one straight block
+                    constexpr bool INSIDE = decltype(inside_tag)::value; // every tap valid: no validity test, clamp or select
+                    constexpr int CS = decltype(stride_tag)::value;      // the box has the compile-time row stride
+                    if constexpr(FAST && FULL && PARIS_FUSED_PIPELINE > 0)
+                    {
+                        // software pipeline over the slices: the LDS reads of the next PARIS_FUSED_PIPELINE slices are in flight while
+                        // slice z is finished
+                        constexpr int AHEAD = PARIS_FUSED_PIPELINE;
                         Tap ring[AHEAD + 1][VX];
                         auto fetch = [&](int z) {
-                            const float z_m = z_of(Z0 + z);
-                            const bool live = static_cast<uint32_t>(Z0 + z) < mcount;
+                            // (the TZ slice coordinates stay in registers: reading them back from LDS per slice to make room for a deeper
+                            // pipeline cost 5 %, profiles/r02_ab_fused_steps.txt)
+                            const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + static_cast<uint32_t>(z)) * g.l_vx_z; // :118
 #pragma unroll
                             for(int j = 0; j < VX; ++j)
-                            {
-                                Tap t;
-                                if constexpr(MODE == 0)
-                                    t = fetch_tap<FD, true, FIXED_STRIDE>(g, box, lds, z_m, col[j]);
-                                else if constexpr(MODE == 1)
-                                {
-                                    t = fetch_tap<FD, false, 0>(g, box, lds, z_m, col[j]);
-                                    t.valid = t.valid && live;
-                                }
-                                else
-                                    t = fetch_tap_general<FD>(g, box, lds, z_m, col[j], live);
-                                ring[z % (AHEAD + 1)][j] = t;
-                            }
+                                ring[z % (AHEAD + 1)][j] = fetch_tap<FD, INSIDE, CS>(g, box, lds, z_m, col[j]);
                         };
 #pragma unroll
-                        for(int z = 0; z < AHEAD && z < ZN; ++z)
+                        for(int z = 0; z < AHEAD && z < TZ; ++z)
                             fetch(z);
 #pragma unroll
-                        for(int z = 0; z < ZN; ++z)
+                        for(int z = 0; z < TZ; ++z)
                         {
-                            if(z + AHEAD < ZN)
+                            if(z + AHEAD < TZ)
                                 fetch(z + AHEAD);
 #pragma unroll
                             for(int j = 0; j < VX; ++j)
-                                c[z][j] = finish_tap<MODE == 0>(col[j], ring[z % (AHEAD + 1)][j]);
+                                elem<VX>(acc[z], j) += finish_tap<INSIDE>(col[j], ring[z % (AHEAD + 1)][j]);
                         }
-                    };
-                    if(mode == 3)
-                    {
+                        return;
+                    }
 #pragma unroll
-                        for(int z = 0; z < ZN; ++z)
+                    for(int z = 0; z < TZ; ++z)
+                    {
+                        if(FULL || static_cast<uint32_t>(z) < mcount) // uniform; no break, so acc stays in registers
+                        {
+                            const float z_m = g.z_base + static_cast<float>(g.m_off + m0 + z) * g.l_vx_z; // :118
 #pragma unroll
                             for(int j = 0; j < VX; ++j)
-                                c[z][j] = 0.f;
+                                elem<VX>(acc[z], j) += voxel_contribution<FD, FAST, INSIDE, CS>(g, box, lds, z_m, col[j]);
+                        }
                     }
-                    else if(mode == 0)
-                        contributions(std::integral_constant<int, 0>{});
-#if PARIS_FUSED_THREE_MODES
-                    else if(mode == 1)
-                        contributions(std::integral_constant<int, 1>{});
-#endif
-                    else
-                        contributions(std::integral_constant<int, 2>{});
-#pragma unroll
-                    for(int z = 0; z < ZN; ++z)
-#pragma unroll
-                        for(int j = 0; j < VX; ++j)
-                            elem<VX>(acc[Z0 + z], j) += c[z][j];
                 };
-                run(std::integral_constant<int, 0>{});
-                if constexpr(PARTS > 1)
-                    run(std::integral_constant<int, 1>{});
-                if constexpr(PARTS > 2)
+                // Wave-uniform choice of the all-valid path (a wave with one boundary lane takes the fast path for all its lanes:
+                // a per-lane branch would run both bodies). Interior tiles -- most of the field of view -- take it.
+                const bool wave_inside = mcount == TZ && g.p_dim_y < (1u << 23) && __all(all_inside ? 1 : 0) != 0;
+                const bool fixed = box.stride == FIXED_STRIDE; // workgroup-uniform
+                using no_stride = std::integral_constant<int, 0>;
+                using the_stride = std::integral_constant<int, FIXED_STRIDE>;
+                if(g.skip_invalid != 0u && __all(all_none ? 1 : 0) != 0)
                 {
-                    run(std::integral_constant<int, 2>{});
-                    run(std::integral_constant<int, 3>{});
+                    // no ray of this projection reaches any column of the wave: every contribution is +0 and the volume holds no -0
+                    // (BpParams::skip_invalid) -- nothing to add. About a tenth of the (wave, projection) pairs of a 2048^3 launch.
                 }
+                else if(wave_inside && fixed)
+                    add_projection(std::true_type{}, std::true_type{}, std::true_type{}, the_stride{});
+                else if(wave_inside)
+                    add_projection(std::true_type{}, std::true_type{}, std::true_type{}, no_stride{});
+                else if(all_fast && mcount == TZ && fixed)
+                    add_projection(std::true_type{}, std::true_type{}, std::false_type{}, the_stride{});
+                else if(all_fast && mcount == TZ)
+                    add_projection(std::true_type{}, std::true_type{}, std::false_type{}, no_stride{});
+                else if(all_fast)
+                    add_projection(std::true_type{}, std::false_type{}, std::false_type{}, no_stride{});
+                else
+                    add_projection(std::false_type{}, std::false_type{}, std::false_type{}, no_stride{});
             }
         }
 #pragma unroll

@@ -788,45 +788,6 @@ namespace
         return t;
     }
 
-    // The general tap (voxel_contribution<FD, false>'s first half): validity from the float coordinates (:65-68, a NaN coordinate is
-    // invalid), rows clamped into the staged box, and a valid tap outside the box read from the detector in global memory. `live`
-    // (workgroup-uniform): the slice exists; taps of slices beyond the volume's last one are invalid.
-    template <bool FD>
-    __device__ __forceinline__ Tap fetch_tap_general(const BpParams& g, const Box& b, const float* lds_box, float z_m, const Column& col, bool live)
-    {
-        Tap t;
-        const float v = v_coordinate<FD>(g, z_m, col.factor);
-        const float y1 = floorf(v);
-        const float y2 = y1 + 1.f;
-        const int y1i = static_cast<int>(y1);
-        t.wy1 = v - y1; // for a valid tap 1 - wy1 == y2 - v bit for bit (see voxel_contribution)
-        t.valid = live && (y1 >= 0.f) && (y2 < col.ymax); // :67-68 (+ x validity)
-        const int rrel = y1i - b.by0;
-        const int bhs_m2 = b.bhs - 2;
-        int rc;
-        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(rc) : "v"(rrel), "v"(max(bhs_m2, 0)));
-        using lds_cptr = const __attribute__((address_space(3))) float*;
-        const int stride4 = b.stride << 2;
-        const uint32_t xaddr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_box)) + (static_cast<uint32_t>(max(col.xoff, 0)) << 2);
-        const uint32_t a1 = static_cast<uint32_t>(__mul24(rc, stride4)) + xaddr;
-        lds_cptr r1 = reinterpret_cast<lds_cptr>(a1);
-        lds_cptr r2 = reinterpret_cast<lds_cptr>(a1 + static_cast<uint32_t>(stride4));
-        t.q11 = r1[0];
-        t.q21 = r1[1];
-        t.q12 = r2[0];
-        t.q22 = r2[1];
-        const bool inbox = col.xoff >= 0 && rrel >= 0 && rrel <= bhs_m2;
-        if(t.valid && !inbox)
-        {
-            const size_t at = static_cast<size_t>(y1i) * g.p_pitch + col.x1i;
-            t.q11 = read_pixel(g, at);
-            t.q21 = read_pixel(g, at + 1);
-            t.q12 = read_pixel(g, at + g.p_pitch);
-            t.q22 = read_pixel(g, at + g.p_pitch + 1);
-        }
-        return t;
-    }
-
     template <bool ALLVALID>
     __device__ __forceinline__ float finish_tap(const Column& col, const Tap& t)
     {
