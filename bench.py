@@ -589,6 +589,10 @@ def main():
                 # kernel's sources have changed since
                 "traffic_is_of_this_kernel": (traffic_sha == kernel_source_sha16()) if traffic is not None else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
+                # achieved is priced on the ALGORITHMIC bytes (8 B for every voxel-update the reference performs); measured traffic
+                # below them = tiles no ray of the projection reaches, which the library leaves untouched (the reference adds +0
+                # there; bit-identical for a library-allocated volume: paris_hip_set_backproject_skip_invalid)
+                "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
                 "kernel": "bp_tile_kernel (one projection per launch, 8 B per voxel-update)",
                 "launches_timed": len(kernel_ms),
             },
