@@ -93,6 +93,17 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def library_sha16():
+    """fingerprint of the built library this process loaded"""
+    import hashlib
+
+    from paris_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(w, budget_s):
     """Times the oracle's backprojection on this host's cores: the workload's geometry, a slab of `slices`
     central slices, as many projections as fit the time budget."""
@@ -140,6 +151,72 @@ def cpu_baseline(w, budget_s):
         "sample": "%s geometry, %d central slices (z %d..%d) x %d projections: backproject %.2f s + %d/%d of "
                   "weight %.2f s and filter %.2f s" % (w["name"], slices, z0, z0 + slices - 1, n, t_b, slices, dz,
                                                        t_w, t_f),
+    }
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_c1():
+    """BASELINE.md section 3 / SURVEY.md 8(d): the WHOLE config-1 job on this host's cores -- 256^3 volume, 360 projections @
+    512 x 512 of the analytic 3-D Shepp-Logan phantom (tests/phantom.py, generated outside the timers), weight / filter /
+    backproject timed separately around the oracle's calls (the restatement of src/openmp/*.cpp, all usable cores)."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import phantom
+    from oracle import oracle as O
+    cores = O.usable_cores()
+    O.lib().po_set_num_threads(cores)
+    w = WORKLOADS["c1"]
+    n, n_proj = w["n_row"], w["n_proj"]
+    det = O.DetectorGeometry(n, n, 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 360.0 / n_proj)
+    nat = O.calculate_volume_geometry(det)
+    dx, dy, dz = w["vol"]
+    l_vx = float(np.float32(nat.l_vx_x) * np.float32(n) / np.float32(dx))
+    vg = O.VolumeGeometry(dx, dy, dz, l_vx, l_vx, l_vx)
+    radius = 0.45 * dx * l_vx
+    fs = O.filter_size(n)
+    k = O.make_filter(fs, det.l_px_row)
+    vol = np.zeros((dz, dy, dx), np.float32)
+    t_w = t_f = t_b = 0.0
+    t_gen0 = time.perf_counter()
+    # the frames are synthesised up front on a thread pool (numpy releases the GIL inside its loops), outside every timer
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        frames = list(pool.map(lambda i: phantom.projection(n, n, 0.2, 0.2, 500.0, 500.0, i * det.delta_phi, radius), range(n_proj)))
+    for i in range(n_proj):
+        p = frames[i]
+        t0 = time.perf_counter()
+        O.weight(p, det)
+        t1 = time.perf_counter()
+        O.apply_filter(p, k, fs)
+        t2 = time.perf_counter()
+        s, c, ds, dt = O.backproject_constants(det, i)
+        O.backproject(vol, p, 0, det, vg, s, c, ds, dt)
+        t3 = time.perf_counter()
+        t_w += t1 - t0
+        t_f += t2 - t1
+        t_b += t3 - t2
+    wall = time.perf_counter() - t_gen0
+    updates = float(dx) * dy * dz * n_proj
+    return {
+        "value": updates / t_b / 1e9, "unit": "GVoxel-updates/s", "cores": cores, "kind": "port",
+        "per_core": updates / t_b / 1e9 / cores, "cpu_model": cpu_model(),
+        "backproject_s": t_b, "weight_s": t_w, "filter_s": t_f,
+        "whole_path_value": updates / (t_b + t_w + t_f) / 1e9,
+        "volume_checksum": float(vol.sum(dtype=np.float64)),
+        "sample": "the whole job of BASELINE config 1: %s, analytic Shepp-Logan frames; backproject timed alone "
+                  "(steady clock around the %d calls), weight and filter listed; %.1f s wall including frame synthesis"
+                  % (w["name"], n_proj, wall),
     }
 
 
@@ -244,6 +321,10 @@ def main():
                     "the bench stream: copy + weight/filter + backproject of all its projections, angles baked in) before the timed "
                     "region and replayed inside it -- for the launch-bound small configurations; kernel times then come from a "
                     "separate eager pass (events cannot be read back from a captured stream)")
+    ap.add_argument("--noskip-step", type=int, default=1, help="1 (default): after the timed region, one more step with "
+                    "paris_hip_set_backproject_skip_invalid(0), reported as roofline.frac_without_skip")
+    ap.add_argument("--cpu-c1", type=int, default=1, help="1 (default, N = 1 only): also time the oracle on the whole BASELINE "
+                    "config-1 job (cpu_baseline_c1, a few seconds of CPU work plus ~20 s of frame synthesis)")
     ap.add_argument("--slices", type=int, default=0, help="rehearsal only: cap the volume depth (0 = the workload's)")
     ap.add_argument("--final-gather", choices=["checksums", "slabs", "off"], default="checksums",
                     help="N > 1, after the timed region and timed separately: the job's one collective. checksums (default): "
@@ -374,13 +455,15 @@ def main():
                     B.backproject(be, rp, d_vol, z_first, det, vol_geo, False, roi is not None, roi)
                     launched.append(rp.idx)
 
-    def step(first_idx, count=None):
+    def step(first_idx, count=None, indices=None):
+        """one pass of the hot path over `count` consecutive projections from first_idx, or over the given projection indices"""
         if shard:
             return sharded_step(first_idx, batch if count is None else count)
-        for j in range(batch if count is None else count):
+        todo = indices if indices is not None else [first_idx + j for j in range(batch if count is None else count)]
+        for j, at in enumerate(todo):
             b = j % nb
             p = projs[b]
-            p.idx = (first_idx + j) % n_proj
+            p.idx = at % n_proj
             work[b, band].copy_(raw[b, band], non_blocking=True)              # stands in for the upload
             if f16:
                 # config 5: weight + filter in one launch that stores the band as IEEE half (no separate conversion pass)
@@ -454,6 +537,19 @@ def main():
         kernel_idx = launched[-len(kernel_ms):] if kernel_ms else []
     else:
         be.backproject_timing_arm(1)
+
+    # ---- one more step with paris_hip_set_backproject_skip_invalid(0): every tile is read and written, also those no ray
+    # reaches -- the kernel's rate on exactly the algorithmic bytes. Its projections are spread over the whole circle.
+    noskip_ms = None
+    if args.noskip_step and not shard:
+        spread = [(j * n_proj) // batch for j in range(batch)] if batch <= n_proj else list(range(batch))
+        be.set_backproject_skip_invalid(False)
+        be.backproject_timing_arm(min(65536, max(1, len(spread))))
+        step(0, indices=spread)
+        noskip_ms = be.backproject_timing_collect()
+        be.set_backproject_skip_invalid(True)
+        be.backproject_timing_arm(1)
+        del launched[-len(spread):]
 
     # ---- extension, outside the headline: the same step with ONE fused launch per batch (paris_hip_backproject_batch)
     fused = None
@@ -538,6 +634,19 @@ def main():
 
     voxels_rank = float(z_count) * out_geo.dim_x * out_geo.dim_y
     voxels_all = float(out_geo.dim_z) * out_geo.dim_x * out_geo.dim_y
+
+    # every rank's own kernel statistics, so that a first multi-GPU run explains itself: a slow rank, a rank on another build
+    # of the kernel, a rank whose slab reads a wider detector band
+    per_rank = None
+    if dist is not None:
+        ms = kernel_ms or [0.0]
+        mine = {"rank": rank, "device": dev_index, "slab": [z_first, z_count], "detector_row_band": [band_first, band_count],
+                "launches": len(kernel_ms), "kernel_ms_min": min(ms), "kernel_ms_mean": sum(ms) / len(ms), "kernel_ms_max": max(ms),
+                "kernel_GVox_per_s": voxels_rank / (sum(ms) / len(ms) * 1e-3) / 1e9 if sum(ms) > 0 else 0.0,
+                "kernel_ms_without_skip": (sum(noskip_ms) / len(noskip_ms)) if noskip_ms else None,
+                "kernel_source_sha16": kernel_source_sha16(), "library_sha16": library_sha16()}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     updates_all = voxels_all * batch * args.steps
 
     if rank == 0:
@@ -593,6 +702,8 @@ def main():
                 # below them = tiles no ray of the projection reaches, which the library leaves untouched (the reference adds +0
                 # there; bit-identical for a library-allocated volume: paris_hip_set_backproject_skip_invalid)
                 "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
+                # the DRAM-side fraction: measured bytes (tiles no ray reaches are not moved) over this run's kernel time
+                "frac_dram": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
                 "kernel": "bp_tile_kernel (one projection per launch, 8 B per voxel-update)",
                 "launches_timed": len(kernel_ms),
             },
@@ -604,6 +715,11 @@ def main():
             out["roofline"]["note"] = ("the %.0f MiB slab stays in the 256 MiB Infinity Cache between launches: `frac` (against the HBM "
                                        "peak, as the contract asks) is not the binding bound here; the measured in-place update rate of a "
                                        "cache-resident buffer is %.0f GB/s" % (4.0 * voxels_rank / 2 ** 20, CACHE_RMW_GBS))
+        if noskip_ms:
+            ns = sum(noskip_ms) / len(noskip_ms)
+            out["roofline"]["frac_without_skip"] = algo_bytes / (ns * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["kernel_ms_without_skip"] = ns
+            out["roofline"]["without_skip_launches"] = len(noskip_ms)
         if octants:
             worst = max(octants, key=lambda o: o["mean_ms"])
             best = min(octants, key=lambda o: o["mean_ms"])
@@ -625,8 +741,14 @@ def main():
             out["final_gather"] = gather
         if dist is not None:
             out["config"]["rank_placement"] = placement
+            out["config"]["per_rank"] = per_rank
+            # the PMC traffic figure is of ONE kernel build: every rank reports the build it ran
+            out["roofline"]["kernel_source_sha16_by_rank"] = [r["kernel_source_sha16"] for r in per_rank]
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
+            out["cpu_baseline"]["cpu_model"] = cpu_model()
+            if args.cpu_c1:
+                out["cpu_baseline_c1"] = cpu_baseline_c1()
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 

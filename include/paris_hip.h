@@ -206,6 +206,14 @@ int paris_hip_set_stage_fusion(paris_hip_ctx* ctx, int enable);
  * neither load nor store their tile; the result is bit-identical. Volumes the library did not allocate, and volumes a
  * paris_hip_memcpy_volume_h2d wrote into, always take every addition. */
 int paris_hip_set_backproject_skip_invalid(paris_hip_ctx* ctx, int enable);
+/* The library learns of writes into a volume only through its own entry points. A caller that writes one some other way -- its own
+ * kernel, a torch tensor over the same memory -- and may have stored a -0 says so with paris_hip_volume_mark_dirty: every volume
+ * that overlaps [d_ptr, d_ptr + bytes) takes every addition from then on (until a paris_hip_memset_volume covers it whole again).
+ * paris_hip_volume_mark_clean is the opposite promise, for ANY device memory, the caller's own included: the range holds no -0
+ * right now (freshly zero-filled; written by nothing but backprojections since) and the caller will mark it dirty before writing
+ * anything else into it. Writing zeros (hipMemset, tensor.zero_()) needs neither call. */
+int paris_hip_volume_mark_dirty(paris_hip_ctx* ctx, const void* d_ptr, size_t bytes);
+int paris_hip_volume_mark_clean(paris_hip_ctx* ctx, const void* d_ptr, size_t bytes);
 
 /* Extension: weighting and row filter of rows [row_first, row_first + row_count) in one launch, explicitly. d_half != NULL:
  * the filtered rows are stored as IEEE half (round to nearest even) into d_half (same row numbering, half_pitch bytes per
@@ -273,8 +281,9 @@ int paris_hip_backproject_batch_f16(paris_hip_ctx* ctx, const uint16_t* d_p, siz
  * (paris_hip_ctx_synchronize, _fence_record, _memcpy_volume_*, _memset_volume, _free, _backproject_batch, a call of the
  * other precision, the timing and tuning calls, paris_hip_flush). The volume is then read and written once per n projections instead of
  * once per projection. Two caveats: work the caller enqueues on the ctx's stream OUTSIDE this API does not see deferred
- * projections (call paris_hip_flush first), and paris_hip_ctx_destroy runs what is still pending only if the volume is still a live
- * device allocation (it is dropped otherwise). Depth 1 (the
+ * projections (call paris_hip_flush first), and paris_hip_ctx_destroy runs what is still pending only into a volume that
+ * paris_hip_malloc_volume of this ctx allocated and paris_hip_free has not taken back (pending projections of any other volume
+ * are dropped: the library cannot know whether that address still belongs to the caller). Depth 1 (the
  * default) is immediate execution. The C++ mirror paris::hip enables depth 16, so PARIS's unchanged per-projection loop
  * (src/main.cpp:98-105) runs at the fused kernel's rate. */
 int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t depth);

@@ -84,15 +84,26 @@ class Backend:
         self._ctx = ctx
         self.device = device
         self._owned = set()
+        self._wrapped = []  # weak references to the owners of wrapped volumes
 
     # ---- lifetime ------------------------------------------------------------------------------------
     def close(self):
         if self._ctx is not None:
+            # projections still deferred into a wrapped (caller-owned) volume: run them while the caller's memory is certainly
+            # still there -- paris_hip_ctx_destroy itself only runs pending work into volumes the library allocated
+            if self._wrapped_alive():
+                self._L.paris_hip_flush(self._ctx)
             for p in list(self._owned):
                 self._L.paris_hip_free(self._ctx, C.c_void_p(p))
             self._owned.clear()
             self._L.paris_hip_ctx_destroy(self._ctx)
             self._ctx = None
+
+    def _wrapped_alive(self):
+        for ref in self._wrapped:
+            if ref is None or ref() is None:  # wrapped without an owner / the
+                return False  # owner was collected: that memory may have changed hands, nothing is run into it
+        return True
 
     def __enter__(self):
         return self
@@ -145,8 +156,33 @@ class Backend:
         """Adopts device memory allocated elsewhere (e.g. a torch tensor's data_ptr())."""
         return Projection(ptr, dim_x, dim_y, idx, phi, pitch=pitch, on_device=True, owner=owner)
 
-    def wrap_volume(self, ptr, dim_x, dim_y, dim_z, off=0, owner=None):
-        return Volume(ptr, dim_x, dim_y, dim_z, off, on_device=True, owner=owner)
+    def wrap_volume(self, ptr, dim_x, dim_y, dim_z, off=0, owner=None, clean=None):
+        """Adopts device memory allocated elsewhere as a volume. The library knows nothing about its contents, so every
+        addition is performed (paris_hip_set_backproject_skip_invalid does not apply) unless the caller vouches with clean=True
+        that it holds no -0 right now (e.g. torch.zeros) and will call volume_mark_dirty before writing anything but zeros into
+        it; clean=False withdraws an earlier promise for the range."""
+        v = Volume(ptr, dim_x, dim_y, dim_z, off, on_device=True, owner=owner)
+        try:
+            import weakref
+            self._wrapped.append(weakref.ref(owner) if owner is not None else None)
+        except TypeError:
+            self._wrapped.append(None)
+        if clean is True:
+            self.volume_mark_clean(v)
+        elif clean is False:
+            self.volume_mark_dirty(v)
+        return v
+
+    def volume_mark_dirty(self, v):
+        """the caller wrote the volume itself and may have stored a -0 (paris_hip_volume_mark_dirty)"""
+        check(self._L.paris_hip_volume_mark_dirty(self._ctx, v.ptr, 4 * v.dim_x * v.dim_y * v.dim_z), "paris_hip_volume_mark_dirty")
+
+    def volume_mark_clean(self, v):
+        """the caller vouches that the volume holds no -0 right now (paris_hip_volume_mark_clean)"""
+        check(self._L.paris_hip_volume_mark_clean(self._ctx, v.ptr, 4 * v.dim_x * v.dim_y * v.dim_z), "paris_hip_volume_mark_clean")
+
+    def memset_volume(self, v):
+        check(self._L.paris_hip_memset_volume(self._ctx, v.ptr, v.dim_x, v.dim_y, v.dim_z), "paris_hip_memset_volume")
 
     def copy_h2d(self, h, d):
         """copy_h2d for projections (carries idx, phi: src/openmp/memory.cpp:60-62) and volumes (off: :73)."""

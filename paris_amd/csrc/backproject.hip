@@ -372,8 +372,8 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + TY - 1u) / TY;
         g.ntz = (g.v_dim_z + g.tz - 1u) / g.tz;
-        g.zchunk = std::max(1u, 256u / std::max(1u, g.tz)); // order 12: chunks of 256 slices
-        uint32_t blocks = grid_blocks(g);
+        g.zchunk = order12_zchunk(g.tz, g.ntz);
+        const uint32_t blocks = static_cast<uint32_t>(grid_blocks(g));
         hipLaunchKernelGGL((bp_tile_kernel<VX, UNROLL, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, g);
     }
 
@@ -409,10 +409,10 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + 15u) / 16u;
         g.ntz = (g.v_dim_z + g.tz - 1u) / g.tz;
-        g.zchunk = std::max(1u, 256u / std::max(1u, g.tz));
+        g.zchunk = order12_zchunk(g.tz, g.ntz);
         hipLaunchKernelGGL((bp_column_state_kernel<FD>), dim3((g.v_dim_x + 255u) / 256u, g.v_dim_y), dim3(256), 0, stream, g,
                            const_cast<float*>(g.colstate));
-        hipLaunchKernelGGL((bp_tile_kernel<4, UNROLL, true, FD, true>), dim3(grid_blocks(g)), dim3(256), g.lds_floats * sizeof(float), stream, g);
+        hipLaunchKernelGGL((bp_tile_kernel<4, UNROLL, true, FD, true>), dim3(static_cast<uint32_t>(grid_blocks(g))), dim3(256), g.lds_floats * sizeof(float), stream, g);
     }
 
     // ---- slice kernel launchers ------------------------------------------------------------------------------
@@ -426,8 +426,8 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + TY - 1u) / TY;
         g.ntz = (g.v_dim_z + NW - 1u) / NW;
-        g.zchunk = std::max(1u, 256u / static_cast<uint32_t>(NW));
-        uint32_t blocks = grid_blocks(g);
+        g.zchunk = order12_zchunk(NW, g.ntz);
+        const uint32_t blocks = static_cast<uint32_t>(grid_blocks(g));
         const uint32_t lds_bytes = g.lds_floats * sizeof(float);
         if(lds_bytes > 64u * 1024u) // beyond the default dynamic-LDS limit (only with a raised box budget): per launch, cheap
             PARIS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bp_slice_kernel<NW, RPL, NT, FD>),
@@ -592,9 +592,13 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     const uint32_t tz_auto = plane > (1ull << 20) ? (v_dim_z <= 512u ? 8u : TZ_DEFAULT) : (plane > (1ull << 18) ? 8u : TZ_DEFAULT);
     const uint32_t tz = ctx->bp_tz ? ctx->bp_tz : tz_auto;
     {
-        // the 1-D grid must hold every tile (narrowest tile: 64 x 4 x tz)
-        const uint64_t tiles = static_cast<uint64_t>((v_dim_x + 63u) / 64u) * ((v_dim_y + 3u) / 4u) * ((v_dim_z + std::min(tz, 8u) - 1u) / std::min(tz, 8u));
-        if(tiles > 0x7fffff00ull)
+        // the 1-D grid must hold every tile of the narrowest, shallowest tiling any kernel uses (64 x 4 x min(tz, 8)), INCLUDING
+        // the padding blocks of the band orders: y tiles rounded up to 8 bands, z tiles to whole chunks
+        const uint32_t tz_min = std::min(tz, 8u);
+        const uint64_t ntx = (v_dim_x + 63u) / 64u, nty = (v_dim_y + 3u) / 4u, ntz = (v_dim_z + tz_min - 1u) / tz_min;
+        const uint64_t zchunk = order12_zchunk(tz_min, static_cast<uint32_t>(ntz));
+        const uint64_t padded = 8ull * ((nty + 7u) / 8u) * ntx * zchunk * ((ntz + zchunk - 1u) / zchunk);
+        if(padded > 0x7fffff00ull)
             return PARIS_HIP_ERROR_UNSUPPORTED;
     }
 

@@ -137,16 +137,25 @@ namespace
     }
 
     // 1-D grid size for the tile mapping in g.order (tile_of_block rejects the padding blocks)
-    inline uint32_t grid_blocks(const BpParams& g)
+    // (64-bit: the padded count of a band order can exceed the tile count by the band and chunk rounding; fill_params has checked
+    // that the worst case over kernels and orders fits a 1-D grid)
+    inline uint64_t grid_blocks(const BpParams& g)
     {
-        const uint32_t total = g.ntx * g.nty * g.ntz;
+        const uint64_t total = static_cast<uint64_t>(g.ntx) * g.nty * g.ntz;
         if(g.order == 5u)
             return ((total + 7u) / 8u) * 8u;
         if(g.order == 8u || g.order == 9u)
-            return 8u * ((g.nty + 7u) / 8u) * g.ntx * g.ntz;
+            return 8ull * ((g.nty + 7u) / 8u) * g.ntx * g.ntz;
         if(g.order == 12u)
-            return 8u * ((g.nty + 7u) / 8u) * g.ntx * g.zchunk * ((g.ntz + g.zchunk - 1u) / g.zchunk);
+            return 8ull * ((g.nty + 7u) / 8u) * g.ntx * g.zchunk * ((g.ntz + g.zchunk - 1u) / g.zchunk);
         return total;
+    }
+
+    // z tiles per chunk of order 12: chunks of 256 slices, never more z tiles than the volume has (a shallow slab would otherwise
+    // launch up to 32 times as many workgroups as it has tiles, all but a few leaving at once: ADVICE r02)
+    inline uint32_t order12_zchunk(uint32_t tz, uint32_t ntz)
+    {
+        return std::min(std::max(1u, 256u / std::max(1u, tz)), std::max(1u, ntz));
     }
 
     // ext-vector twins of float/float2/float4 for the nontemporal builtins

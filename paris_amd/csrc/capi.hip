@@ -168,6 +168,33 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
     if(ctx->upload_stream != nullptr)
         (void)hipStreamSynchronize(ctx->upload_stream);
     ctx->pending_weight.active = false; // a weighting nobody filtered or read: dropped with the ctx
+    if(ctx->defer_count != 0)
+    {
+        // Projections still deferred belong to key_v. Every library entry point that reads or frees a volume has flushed them
+        // already, so they are pending only if the caller touched the volume some other way (own kernel, torch tensor, plain
+        // hipFree). They are run only into a volume THIS ctx allocated and has not freed (paris_hip_malloc_volume's bookkeeping):
+        // for any other address "is a live device allocation" does not say whose -- a wrapped tensor released to a caching
+        // allocator may already back something else -- so those are dropped (callers of wrapped volumes call paris_hip_flush
+        // before they let go of the memory; paris_amd.backend.Backend.close does). First thing in destroy: the launch needs
+        // the ctx's tables, ring and stream intact.
+        bool ours = false;
+        {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(ctx->key_v);
+            const size_t bytes = static_cast<size_t>(ctx->key_dims[0]) * ctx->key_dims[1] * ctx->key_dims[2] * sizeof(float);
+            auto it = ctx->volume_allocs.upper_bound(a);
+            if(it != ctx->volume_allocs.begin())
+            {
+                --it;
+                ours = a >= it->first && a + bytes <= it->first + it->second;
+            }
+        }
+        if(ours)
+        {
+            (void)paris_hip_flush_deferred(ctx);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+        ctx->defer_count = 0;
+    }
     for(auto& kv : ctx->plans)
     {
         (void)hipFree(kv.second.d_twiddle);
@@ -193,22 +220,6 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
     {
         (void)hipEventDestroy(kv.second.released);
         (void)hipHostFree(kv.second.ptr);
-    }
-    if(ctx->defer_count != 0)
-    {
-        // Projections still deferred belong to key_v. Every library entry point that reads or frees a volume has flushed them
-        // already, so they are pending only if the caller touched the volume some other way (own kernel, torch tensor, plain
-        // hipFree). Run them if key_v is still a live device allocation -- the caller's later reads then see every projection --
-        // and drop them if it is gone (writing into freed memory would be worse than losing them).
-        hipPointerAttribute_t attr{};
-        const bool live = hipPointerGetAttributes(&attr, ctx->key_v) == hipSuccess && attr.type == hipMemoryTypeDevice;
-        (void)hipGetLastError();
-        if(live)
-        {
-            (void)paris_hip_flush_deferred(ctx);
-            (void)hipStreamSynchronize(ctx->stream);
-        }
-        ctx->defer_count = 0;
     }
     for(auto& kv : ctx->upload_targets)
         (void)hipEventDestroy(kv.second.last_use);
@@ -382,6 +393,22 @@ extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, u
     return PARIS_HIP_SUCCESS;
 }
 
+namespace
+{
+    void erase_overlapping(std::map<uintptr_t, size_t>& m, uintptr_t a, size_t bytes)
+    {
+        for(auto it = m.begin(); it != m.end();)
+            it = (a < it->first + it->second && it->first < a + bytes) ? m.erase(it) : std::next(it);
+    }
+
+    // [p, p + bytes) no longer belongs to a volume of this ctx
+    void forget_volume_range(paris_hip_ctx* ctx, const void* p, size_t bytes)
+    {
+        erase_overlapping(ctx->clean_volumes, reinterpret_cast<uintptr_t>(p), bytes);
+        erase_overlapping(ctx->volume_allocs, reinterpret_cast<uintptr_t>(p), bytes);
+    }
+}
+
 extern "C" int paris_hip_memset_volume(paris_hip_ctx* ctx, float* d_ptr, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z)
 {
     if(int rc = paris_hip_flush_deferred(ctx))
@@ -392,7 +419,40 @@ extern "C" int paris_hip_memset_volume(paris_hip_ctx* ctx, float* d_ptr, uint32_
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     const size_t bytes = static_cast<size_t>(dim_x) * dim_y * dim_z * sizeof(float);
     PARIS_HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, ctx->stream));
-    return paris_hip_finish(ctx); // (zeros written into a listed volume leave it clean; one that was taken off the list stays off)
+    // zeros written into a listed volume leave it clean; a volume of this ctx that was taken off the list (host upload,
+    // paris_hip_volume_mark_dirty) is listed again when the fill covers it whole: every voxel is +0 once more
+    auto mine = ctx->volume_allocs.find(reinterpret_cast<uintptr_t>(d_ptr));
+    if(mine != ctx->volume_allocs.end() && mine->second == bytes)
+        ctx->clean_volumes[mine->first] = bytes;
+    return paris_hip_finish(ctx);
+}
+
+// Extension (include/paris_hip.h): the caller wrote [d_ptr, d_ptr + bytes) itself (own kernel, a torch tensor over the same
+// memory) and the values may include -0 -- volumes that overlap the range always take every addition from now on
+extern "C" int paris_hip_volume_mark_dirty(paris_hip_ctx* ctx, const void* d_ptr, size_t bytes)
+{
+    if(int rc = paris_hip_flush_deferred(ctx)) // pending projections were enqueued under the old promise: same result either way, but keep the order simple
+        return rc;
+    if(ctx == nullptr || d_ptr == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    erase_overlapping(ctx->clean_volumes, reinterpret_cast<uintptr_t>(d_ptr), bytes ? bytes : 1u);
+    return PARIS_HIP_SUCCESS;
+}
+
+// Extension: the caller vouches that [d_ptr, d_ptr + bytes) holds no -0 right now (freshly zero-filled, or written by nothing but
+// backprojections since): backprojections into it may skip the tiles no ray reaches. Also for memory the library did not allocate.
+extern "C" int paris_hip_volume_mark_clean(paris_hip_ctx* ctx, const void* d_ptr, size_t bytes)
+{
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
+    if(ctx == nullptr || d_ptr == nullptr || bytes == 0)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_ptr);
+    if(paris_hip_volume_is_clean(ctx, d_ptr, bytes))
+        return PARIS_HIP_SUCCESS;
+    erase_overlapping(ctx->clean_volumes, a, bytes); // entries are kept disjoint: the lookup tests one of them
+    ctx->clean_volumes[a] = bytes;
+    return PARIS_HIP_SUCCESS;
 }
 
 extern "C" int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, float** d_ptr)
@@ -412,6 +472,10 @@ extern "C" int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint3
         return static_cast<int>(err);
     }
     *d_ptr = static_cast<float*>(p);
+    // an entry that overlaps the new allocation is stale (its memory was released behind the library's back and the address
+    // range has been handed out again): it must neither vouch for the new volume nor shadow it
+    forget_volume_range(ctx, p, bytes);
+    ctx->volume_allocs[reinterpret_cast<uintptr_t>(p)] = bytes;
     ctx->clean_volumes[reinterpret_cast<uintptr_t>(p)] = bytes;
     return paris_hip_finish(ctx);
 }
@@ -432,9 +496,7 @@ namespace
     // a write from outside the backprojection kernels into [p, p + bytes): volumes it touches are no longer known to be free of -0
     void volume_written(paris_hip_ctx* ctx, const void* p, size_t bytes)
     {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-        for(auto it = ctx->clean_volumes.begin(); it != ctx->clean_volumes.end();)
-            it = (a < it->first + it->second && it->first < a + bytes) ? ctx->clean_volumes.erase(it) : std::next(it);
+        erase_overlapping(ctx->clean_volumes, reinterpret_cast<uintptr_t>(p), bytes);
     }
 }
 
@@ -446,7 +508,6 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
         return PARIS_HIP_SUCCESS;
     if(int rc = paris_hip_flush_pending_weight(ctx))
         return rc;
-    ctx->clean_volumes.erase(reinterpret_cast<uintptr_t>(d_ptr));
     auto filt = ctx->filters.find(static_cast<const float*>(d_ptr));
     if(filt != ctx->filters.end())
     {
@@ -484,6 +545,19 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
             if(int rc = paris_hip_flush_deferred(ctx))
                 return rc;
         (void)hipGetLastError();
+    }
+    {
+        // nothing of the allocation may stay listed as a volume (clean or not): by range, whatever sub-ranges were marked
+        auto mine = ctx->volume_allocs.find(reinterpret_cast<uintptr_t>(d_ptr));
+        size_t size = mine != ctx->volume_allocs.end() ? mine->second : 0u;
+        if(size == 0u)
+        {
+            void* base = nullptr;
+            if(hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, d_ptr) != hipSuccess)
+                size = 1u;
+            (void)hipGetLastError();
+        }
+        forget_volume_range(ctx, d_ptr, size);
     }
     paris_hip_forget_upload_target(ctx, d_ptr);
     PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -551,6 +625,8 @@ extern "C" int paris_hip_memcpy_projection_h2d(paris_hip_ctx* ctx, float* d_dst,
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
                                    hipMemcpyHostToDevice, ctx->stream));
+    if(int rc = paris_hip_note_projection_use(ctx, d_dst, d_pitch * dim_y)) // a later upload into the buffer must not overtake this copy
+        return rc;
     return paris_hip_finish(ctx);
 }
 
@@ -582,11 +658,16 @@ extern "C" int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, siz
     auto target = ctx->upload_targets.find(d_dst);
     if(target == ctx->upload_targets.end())
     {
+        // First upload into this buffer: nothing has been recorded for it yet, but work already queued on the compute stream
+        // may read or write it (a frame put there with paris_hip_memcpy_projection_h2d and still being filtered, say) -- the
+        // upload waits for everything queued so far, once per buffer.
         paris_hip_ctx::upload_target t;
         PARIS_HIP_TRY(hipEventCreateWithFlags(&t.last_use, hipEventDisableTiming));
+        PARIS_HIP_TRY(hipEventRecord(t.last_use, ctx->stream));
+        t.used = true;
         target = ctx->upload_targets.emplace(d_dst, t).first;
     }
-    else if(target->second.used)
+    if(target->second.used)
         PARIS_HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, target->second.last_use, 0));
     target->second.bytes = std::max(target->second.bytes, d_pitch * dim_y);
     hipEvent_t done = ctx->upload_events[ctx->uploads++ % ctx->upload_events.size()];
@@ -608,6 +689,8 @@ extern "C" int paris_hip_memcpy_projection_d2h(paris_hip_ctx* ctx, float* h_dst,
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     PARIS_HIP_TRY(hipMemcpy2DAsync(h_dst, h_pitch, d_src, d_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
                                    hipMemcpyDeviceToHost, ctx->stream));
+    if(int rc = paris_hip_note_projection_use(ctx, d_src, d_pitch * dim_y))
+        return rc;
     return paris_hip_finish(ctx);
 }
 

@@ -61,6 +61,9 @@ struct paris_hip_ctx
     // backprojections since (base address -> bytes). A host upload into one removes it; memory the library did not allocate is
     // never listed.
     std::map<uintptr_t, size_t> clean_volumes;
+    // every volume paris_hip_malloc_volume handed out and paris_hip_free has not taken back (base address -> bytes): the only
+    // memory paris_hip_ctx_destroy will run still-deferred projections into (a foreign address may have changed hands)
+    std::map<uintptr_t, size_t> volume_allocs;
     int bp_lean_div = 1; // share one reciprocal between the two per-column divisions by s + d_so when the operands are in range
     std::map<uint32_t, bool> fastdiv_exact; // divisor bits -> exhaustive check result
     bool filter_lds_attr_set = false;
@@ -159,10 +162,9 @@ inline int paris_hip_note_projection_use(paris_hip_ctx* ctx, const void* d_p, si
         return PARIS_HIP_SUCCESS;
     const char* lo = static_cast<const char*>(d_p);
     const char* hi = lo + (bytes ? bytes : 1u);
-    auto it = ctx->upload_targets.upper_bound(d_p); // first target that starts behind lo; the one before may still reach into the range
-    if(it != ctx->upload_targets.begin())
-        --it;
-    for(; it != ctx->upload_targets.end() && static_cast<const char*>(it->first) < hi; ++it)
+    // Targets may overlap (a driver uploads to interior band pointers that change per task), so ANY earlier-starting target can
+    // still reach into the range: all targets that start before hi are tested (a handful of slots per ctx).
+    for(auto it = ctx->upload_targets.begin(); it != ctx->upload_targets.end() && static_cast<const char*>(it->first) < hi; ++it)
     {
         if(static_cast<const char*>(it->first) + it->second.bytes <= lo)
             continue;

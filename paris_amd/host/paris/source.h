@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <fstream>
 #include <iterator>
 #include <memory>
@@ -301,6 +302,8 @@ namespace paris
                 std::unique_lock<std::mutex> lock{m_};
                 for(;;)
                 {
+                    if(failed_ && k >= produced_)
+                        std::rethrow_exception(failed_); // the shared stream died at frame produced_: every consumer reports it
                     if(ended_ && k >= end_)
                         return frame_info{};
                     if(k < produced_)
@@ -317,7 +320,19 @@ namespace paris
                     {
                         producing_ = true;
                         lock.unlock();
-                        auto fresh = produce(k);
+                        std::shared_ptr<const entry> fresh;
+                        try { fresh = produce(k); }
+                        catch(...)
+                        {
+                            // an I/O or allocation error while reading frame k (an angle file shorter than the frame set:
+                            // std::out_of_range; bad_alloc): the other consumers are parked in cv_.wait() for this frame and
+                            // must not wait for ever -- record the error, wake them (each rethrows it), rethrow here
+                            lock.lock();
+                            producing_ = false;
+                            failed_ = std::current_exception();
+                            cv_.notify_all();
+                            throw;
+                        }
                         lock.lock();
                         producing_ = false;
                         if(fresh)
@@ -428,6 +443,7 @@ namespace paris
         std::vector<std::shared_ptr<const entry>> ring_;
         std::uint64_t produced_ = 0, end_ = 0;
         bool producing_ = false, ended_ = false;
+        std::exception_ptr failed_; // set once, under m_, when produce() threw
         counters stats_;
     };
 }

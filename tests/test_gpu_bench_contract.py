@@ -25,7 +25,7 @@ def test_single_gpu_line():
                         "--cpu-budget", "2", "--fused-steps", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr
     d = last_json_line(r.stdout)
-    for k in REQUIRED + ["cpu_baseline", "fused_extension"]:
+    for k in REQUIRED + ["cpu_baseline", "cpu_baseline_c1", "fused_extension"]:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "GVoxel-updates/s" and d["value"] > 0 and d["vs_baseline"] is None
@@ -43,7 +43,15 @@ def test_single_gpu_line():
     fr = d["fused_extension"]["roofline"]
     assert fr is None or (fr["bound"] == "valu_issue" and abs(fr["frac"] - fr["achieved"] / fr["peak"]) < 1e-12)
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["cpu_model"]
+    # the skip-off leg: one more step (120 launches here) with every tile read and written; the DRAM-side fraction needs a
+    # committed PMC profile of this workload (none for config 1: null)
+    assert rf["without_skip_launches"] == 120 and rf["frac_without_skip"] > 0 and rf["kernel_ms_without_skip"] > 0
+    assert "frac_dram" in rf and (rf["frac_dram"] is None) == (rf["traffic"] is None)
+    # the whole config-1 job on the host's cores, backprojection timed alone
+    c1 = d["cpu_baseline_c1"]
+    assert c1["kind"] == "port" and c1["cores"] >= 1 and c1["value"] > 0 and c1["backproject_s"] > 0 and c1["cpu_model"]
+    assert abs(c1["value"] - 256.0 ** 3 * 360 / c1["backproject_s"] / 1e9) < 1e-9 * c1["value"]
 
 
 def test_two_rank_rehearsal():
@@ -63,6 +71,11 @@ def test_two_rank_rehearsal():
     assert fg["rccl_ranks_seen"] == 2 and fg["mode"] == "checksums" and len(fg["slab_checksums"]) == 2
     assert abs(fg["checksum_of_checksums"] - sum(fg["slab_checksums"])) <= 1e-9 * max(1.0, abs(fg["checksum_of_checksums"]))
     assert [e["rank"] for e in d["config"]["rank_placement"]] == [0, 1]
+    # every rank reports its own kernel statistics and the kernel build it ran
+    pr = d["config"]["per_rank"]
+    assert [e["rank"] for e in pr] == [0, 1] and [e["slab"] for e in pr] == [[0, 128], [128, 128]]
+    assert all(e["launches"] == 360 and 0 < e["kernel_ms_min"] <= e["kernel_ms_mean"] <= e["kernel_ms_max"] for e in pr)
+    assert len(set(d["roofline"]["kernel_source_sha16_by_rank"])) == 1 and len(set(e["library_sha16"] for e in pr)) == 1
 
 
 def test_two_rank_rehearsal_gathers_slabs():

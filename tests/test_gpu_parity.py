@@ -1329,6 +1329,219 @@ def test_full_size_2048_cube_properties(oracle):
         del fused, full
 
 
+def device_view(torch, v, dev):
+    """a torch tensor over a library-allocated volume (z, y, x): the same memory, no copy"""
+    class _Mem:
+        def __init__(self, ptr, shape):
+            self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(_Mem(v.ptr, (v.dim_z, v.dim_y, v.dim_x)), device=dev)
+
+
+@pytest.mark.parametrize("n,n_proj,idxs", [(2048, 1440, (100, 470, 1010)), (1024, 720, (50, 235, 505))])
+def test_full_size_skip_on_equals_skip_off(oracle, n, n_proj, idxs):
+    """VERDICT r02 (weak 2): the bench's headline path at its full size -- a LIBRARY-allocated n^3 volume (known to hold no -0, so
+    waves whose tile no ray reaches leave it untouched), the default tile order and depth -- against the same launches with
+    paris_hip_set_backproject_skip_invalid(0), compared on the device bit for bit (int32 views: the sign of every zero included);
+    then the fused batch with the skip on against the same. Projections from a fast octant (25 deg) and the two slowest
+    (117.5, 252.5 deg) of BENCH_r02's per-octant table. The oracle pins a crop at the far corner (outside the field of view:
+    skipped tiles) and one at the centre. BASELINE configs 3 and 2."""
+    import torch
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < (3 * 4 * n ** 3 + (4 << 30)):
+        pytest.skip("needs %d GiB of free HBM" % ((3 * 4 * n ** 3 >> 30) + 4))
+    g = (n, n, 0.2, 0.2, 0, 0, 500, 500, 360.0 / n_proj)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    l_vx = float(np.float32(nat.l_vx_x))
+    vg, ovg = B.VolumeGeometry(n, n, n, l_vx, l_vx, l_vx), oracle.VolumeGeometry(n, n, n, l_vx, l_vx, l_vx)
+    dev = torch.device("cuda", 0)
+    frames = [oracle.lcg_projection(n, n, i) - np.float32(0.5) for i in idxs]
+    with B.Backend(0, stream=torch.cuda.current_stream(dev).cuda_stream, synchronous=False) as abe:
+        stack = torch.from_numpy(np.stack(frames)).to(dev)
+        projs = [abe.wrap_projection(stack[j].data_ptr(), n * 4, n, n, idx=i, owner=stack) for j, i in enumerate(idxs)]
+        v_on = abe.make_volume_device(n, n, n)
+        v_off = abe.make_volume_device(n, n, n)
+        t_on, t_off = device_view(torch, v_on, dev), device_view(torch, v_off, dev)
+        abe.set_backproject_skip_invalid(True)
+        for p in projs:
+            B.backproject(abe, p, v_on, 0, det, vg, False, False, None)
+        abe.set_backproject_skip_invalid(False)
+        for p in projs:
+            B.backproject(abe, p, v_off, 0, det, vg, False, False, None)
+        abe.synchronize()
+        assert torch.equal(t_on.view(torch.int32), t_off.view(torch.int32))
+        nonzero = int(torch.count_nonzero(t_off))
+        assert 0.5 * n ** 3 < nonzero < n ** 3  # the grid's corners lie outside the field of view: there is something to skip
+        # the fused batch, skip on, into the re-zeroed (whole fill: clean again) first volume
+        abe.set_backproject_skip_invalid(True)
+        abe.memset_volume(v_on)
+        sc = [B.stage_angle(det, i) for i in idxs]
+        abe.backproject_batch(stack.data_ptr(), n * 4, n * n * 4, len(idxs), n, n, v_on, 0, det, vg, False, None,
+                              [s for s, _ in sc], [c for _, c in sc], 0.0, 0.0)
+        abe.synchronize()
+        assert torch.equal(t_on.view(torch.int32), t_off.view(torch.int32))
+        for (x1, y1, z1) in ((n - 64, n - 64, n - 8), (n // 2 - 32, n // 2 - 32, n // 2)):
+            crop = t_on[z1:z1 + 8, y1:y1 + 64, x1:x1 + 64].cpu().numpy()
+            roi = oracle.RegionOfInterest(x1, x1 + 64, y1, y1 + 64, z1, z1 + 8)
+            want = np.zeros((8, 64, 64), np.float32)
+            for i, f in zip(idxs, frames):
+                s, c, ds, dt = oracle.backproject_constants(odet, i)
+                oracle.backproject(want, f, 0, odet, ovg, s, c, ds, dt, roi)
+            assert_bit_equal(crop, want)
+        del t_on, t_off
+
+
+def test_volume_mark_dirty_and_clean(be, oracle):
+    """paris_hip_volume_mark_dirty / _mark_clean: the library cannot see writes that do not go through it.
+    A library volume the caller scribbled -0 into through a torch view takes every addition once it is marked dirty (bit-equal
+    to the oracle started from the same values: no -0 survives); a whole-volume paris_hip_memset_volume lists it as clean again;
+    a torch.zeros volume wrapped with clean=True may skip and equals the oracle; one wrapped without the promise takes every
+    addition."""
+    import torch
+    g = (64, 48, 0.4, 0.4, 1.5, -2.0, 200, 150, 23.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    dims = (96, 72, 192)
+    dz, dy, dx = dims
+    l_vx = float(nat.l_vx_x)
+    vg = B.VolumeGeometry(dx, dy, dz, l_vx * 1.1, l_vx * 2.6, l_vx * 1.7)
+    ovg = oracle.VolumeGeometry(dx, dy, dz, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    projs = [oracle.lcg_projection(64, 48, i) - np.float32(0.5) for i in range(5)]
+    start = np.zeros(dims, np.float32)
+    start[::3, ::5, ::7] = np.float32(-0.0)
+    want_zero = oracle_backproject_all(oracle, projs, odet, ovg, dims)
+    want_up = start.copy()
+    for i, p in enumerate(projs):
+        s, c, ds, dt = oracle.backproject_constants(odet, i)
+        oracle.backproject(want_up, p, 0, odet, ovg, s, c, ds, dt, None)
+    dev = torch.device("cuda", 0)
+    minus = torch.from_numpy(start).to(dev)
+
+    def add_all(d_v):
+        for i, p in enumerate(projs):
+            d_p = to_device(be, p, idx=i)
+            B.backproject(be, d_p, d_v, 0, det, vg, False, False, None)
+            be.free(d_p)
+        return volume_to_host(be, d_v)
+
+    be.set_backproject_skip_invalid(True)
+    # (1) foreign write + mark_dirty: every addition is made
+    d_v = be.make_volume_device(dx, dy, dz)
+    be.synchronize()
+    view = device_view(torch, d_v, dev)
+    view.copy_(minus)
+    torch.cuda.synchronize()
+    be.volume_mark_dirty(d_v)
+    assert_bit_equal(add_all(d_v), want_up)
+    # (2) a whole-volume memset lists it again; the result is the zero-start one either way
+    be.memset_volume(d_v)
+    assert_bit_equal(add_all(d_v), want_zero)
+    # (3) the hazard the call exists for: the same foreign write WITHOUT the call leaves -0 in the tiles nothing reaches
+    be.memset_volume(d_v)
+    be.synchronize()
+    view.copy_(minus)
+    torch.cuda.synchronize()
+    got = add_all(d_v)
+    assert np.signbit(got[got == 0]).sum() > 0, "the skip did not happen (or the tiles were not skipped as a whole)"
+    del view
+    be.free(d_v)
+    # (4) wrapped memory: no promise -> every addition; clean=True -> may skip, same bits as the oracle from zero
+    t = minus.clone()
+    assert_bit_equal(add_all(be.wrap_volume(t.data_ptr(), dx, dy, dz, owner=t)), want_up)
+    z = torch.zeros(dims, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    w = be.wrap_volume(z.data_ptr(), dx, dy, dz, owner=z, clean=True)
+    assert_bit_equal(add_all(w), want_zero)
+    be.volume_mark_dirty(w)
+
+
+def test_ctx_destroy_runs_pending_work_only_into_its_own_volumes(oracle):
+    """projections still deferred when the ctx is destroyed are run into a volume the ctx allocated (and has
+    not freed), and dropped for any other address -- the library cannot know whether foreign memory still belongs to the
+    caller. Raw C ABI, no Python-side flush."""
+    import torch
+    L = _lib.load()
+    det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
+    vg, ovg = B.calculate_volume_geometry(det), oracle.calculate_volume_geometry(odet)
+    dims = (vg.dim_z, vg.dim_y, vg.dim_x)
+    projs = [oracle.lcg_projection(64, 48, i) - np.float32(0.5) for i in range(3)]
+    want = oracle_backproject_all(oracle, projs, odet, ovg, dims)
+    dev = torch.device("cuda", 0)
+    frames = torch.from_numpy(np.stack(projs)).to(dev)
+    foreign = torch.zeros(dims, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    roi = B.RegionOfInterest()
+
+    def pending_into(ctx, d_v):
+        assert L.paris_hip_set_backproject_deferral(ctx, 8) == 0
+        for i in range(3):
+            s, c = B.stage_angle(det, i)
+            assert L.paris_hip_backproject(ctx, frames[i].data_ptr(), 64 * 4, 64, 48, d_v, vg.dim_x, vg.dim_y, vg.dim_z, 0,
+                                           C.byref(det), C.byref(vg), 0, C.byref(roi), s, c, det.delta_s * det.l_px_row,
+                                           det.delta_t * det.l_px_col) == 0
+
+    ctx = C.c_void_p()
+    assert L.paris_hip_ctx_create(0, None, 0, C.byref(ctx)) == 0
+    own = C.c_void_p()
+    assert L.paris_hip_malloc_volume(ctx, vg.dim_x, vg.dim_y, vg.dim_z, C.byref(own)) == 0
+    pending_into(ctx, own)
+    assert L.paris_hip_ctx_destroy(ctx) == 0  # the volume outlives the ctx (never freed through it)
+    got = device_view(torch, B.Volume(own.value, vg.dim_x, vg.dim_y, vg.dim_z, on_device=True), dev).cpu().numpy()
+    assert_bit_equal(got, want)
+
+    ctx = C.c_void_p()
+    assert L.paris_hip_ctx_create(0, None, 0, C.byref(ctx)) == 0
+    pending_into(ctx, C.c_void_p(foreign.data_ptr()))
+    assert L.paris_hip_ctx_destroy(ctx) == 0
+    torch.cuda.synchronize()
+    assert int(torch.count_nonzero(foreign.view(torch.int32))) == 0  # dropped, nothing written
+    # an explicit flush is the caller's way to get them (what Backend.close does for wrapped volumes whose owner is alive)
+    ctx = C.c_void_p()
+    assert L.paris_hip_ctx_create(0, None, 0, C.byref(ctx)) == 0
+    pending_into(ctx, C.c_void_p(foreign.data_ptr()))
+    assert L.paris_hip_flush(ctx) == 0
+    assert L.paris_hip_free(ctx, own) == 0  # the first ctx's volume: an address this ctx does not know is simply released
+    assert L.paris_hip_ctx_destroy(ctx) == 0
+    torch.cuda.synchronize()
+    assert_bit_equal(foreign.cpu().numpy(), want)
+
+
+def test_shallow_slab_on_a_wide_plane(be, oracle):
+    """2048 x 2048 x 8 -- one z tile under tile order 12, whose chunk of 256 slices used to pad the grid to 32 times
+    the tile count. Default path and fused batch against oracle crops."""
+    n = 2048
+    g = (n, n, 0.2, 0.2, 0, 0, 500, 500, 0.25)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
+    ovg = oracle.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
+    v_offset, nz = 1000, 8
+    idxs = (7, 400)
+    projs = [oracle.lcg_projection(n, n, i) - np.float32(0.5) for i in idxs]
+    stack = be.make_projection_device(n, n * len(idxs))
+    be.copy_h2d(B.Projection(np.ascontiguousarray(np.concatenate(projs)), n, n * len(idxs)), stack)
+    sc = [B.stage_angle(det, i) for i in idxs]
+    for fused in (False, True):
+        d_v = be.make_volume_device(n, n, nz)
+        if fused:
+            be.backproject_batch(stack.ptr, stack.pitch, stack.pitch * n, len(idxs), n, n, d_v, v_offset, det, vg, False, None,
+                                 [s for s, _ in sc], [c for _, c in sc], 0.0, 0.0)
+        else:
+            for j, i in enumerate(idxs):
+                p = be.wrap_projection(stack.ptr + j * stack.pitch * n, stack.pitch, n, n, idx=i)
+                B.backproject(be, p, d_v, v_offset, det, vg, False, False, None)
+        got = volume_to_host(be, d_v)
+        be.free(d_v)
+        for (x1, y1) in ((0, 0), (1984, 1000), (960, 1984)):
+            roi = oracle.RegionOfInterest(x1, x1 + 64, y1, y1 + 64, 0, n)
+            want = np.zeros((nz, 64, 64), np.float32)
+            for i, p in zip(idxs, projs):
+                s, c, ds, dt = oracle.backproject_constants(odet, i)
+                oracle.backproject(want, p, v_offset, odet, ovg, s, c, ds, dt, roi)
+            assert_bit_equal(got[:, y1:y1 + 64, x1:x1 + 64], want)
+    be.free(stack)
+
+
 def test_config3_4_geometry_slab_crops(be, oracle):
     """BASELINE configs 3 / 4 geometry (2048^2 detector, 2048^3 grid): part of slab 7 of 8 (v_offset 1792, 24 slices =
     one and a half tiles deep) through the default kernel path (y-band tile order, 4-pixel staging, fast division),

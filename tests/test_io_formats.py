@@ -266,3 +266,30 @@ def test_shared_frames_read_each_frame_once(io, tmp_path, capacity, delays, expe
         assert produced == len(keep)                       # every kept frame converted from the files exactly once
         assert served + reread == nt * len(keep)           # every request answered
         assert (reread > 0) == expect_reread
+
+
+@pytest.mark.timeout(120)
+def test_shared_frames_error_reaches_every_consumer(io, tmp_path):
+    """when reading a frame fails inside the shared source (here the angle file is shorter than the frame set, so
+    the lookup of frame 4's angle throws, as the reference's own loop would run off its angle vector: src/source.cpp:115-118),
+    the consumers parked on that frame must be woken and report the error too -- not wait for ever. One consumer is slowed
+    down so that it is certainly parked behind the producer at some point."""
+    io.paris_io_shared_scan.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p,
+                                        _u32p, C.c_uint32, C.c_uint32, _u32p, _u32p, _fp, _fp, C.POINTER(C.c_uint64)]
+    d = tmp_path / "proj"
+    d.mkdir()
+    w, h = 5, 4
+    fr = np.arange(8 * h * w, dtype=np.float32).reshape(8, h, w)
+    (d / "a.his").write_bytes(F.his_file_bytes(fr, 128, 0))
+    ang = tmp_path / "ang.txt"
+    ang.write_text("0 10 20")  # + the reader's trailing duplicate (Q15): 4 angles for 8 frames
+    for delays in ((0, 0), (0, 2000), (2000, 0)):
+        cap, nt = 16, 2
+        n = (C.c_uint32 * nt)()
+        idx = (C.c_uint32 * (nt * cap))()
+        phi = (C.c_float * (nt * cap))()
+        data = np.zeros((nt, cap, h, w), np.float32)
+        counters = (C.c_uint64 * 3)()
+        rc = io.paris_io_shared_scan(str(d).encode(), 1, str(ang).encode(), 1, w, h, nt, (C.c_uint32 * nt)(0, 0), (C.c_uint32 * nt)(h, h),
+                                     (C.c_uint32 * nt)(*delays), 4, cap, n, idx, phi, data.ctypes.data_as(_fp), counters)
+        assert rc == 1  # every worker came back (join returned) and at least one reported the failure

@@ -106,7 +106,7 @@ def _gather_worker(rank, world, port, result_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_final_gather_and_placement(tmp_path, world):
     import torch.multiprocessing as mp
     result = str(tmp_path / "g.npy")
@@ -132,7 +132,7 @@ def test_device_of_rank():
     assert sharding.check_placement([dict(a, uuid="x"), dict(b, uuid="y")]) == 2
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_slab_sharding_matches_single_rank(tmp_path, world):
     import torch.multiprocessing as mp
     result = str(tmp_path / "r.npy")
@@ -156,9 +156,16 @@ def test_partition_rule():
     assert sharding.slab_of_task(one, 0) == (0, 61)
     with pytest.raises(ValueError):
         sharding.slab_of_task(info, 8)
+    # BASELINE config 4: 2048 slices on 8 GPUs = 8 x 256, no remainder; a 2050-slice grid puts its 2 extra slices on rank 7
+    c4 = sharding.make_subvolume_info(B.VolumeGeometry(2048, 2048, 2048, 1, 1, 1), 8)
+    assert [sharding.slab_of_task(c4, t) for t in range(8)] == [(256 * t, 256) for t in range(8)] and c4.geo.remainder == 0
+    odd = sharding.make_subvolume_info(B.VolumeGeometry(2048, 2048, 2050, 1, 1, 1), 8)
+    slabs = [sharding.slab_of_task(odd, t) for t in range(8)]
+    assert slabs[:7] == [(256 * t, 256) for t in range(7)] and slabs[7] == (1792, 258) and odd.geo.remainder == 2
+    assert [sharding.tasks_of_rank(odd, r, 8) for r in range(8)] == [[r] for r in range(8)]
 
 
-def _filter_shard_worker(rank, world, port, result_path):
+def _filter_shard_worker(rank, world, port, n_proj, result_path):
     """f4, second half: rank r weights + filters projections r, r + N, ... only; per group of N the ranks exchange the
     detector rows of each other's bands (paris_amd.sharding.exchange_filtered, bench.py --filter-shard); every rank then
     backprojects all frames into its slab from buffers whose rows outside its band are NaN. Oracle arithmetic, gloo."""
@@ -174,7 +181,7 @@ def _filter_shard_worker(rank, world, port, result_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = (64, 48, 0.2, 0.25, 1.5, -0.75, 100, 200, 45)
-    n_proj = 7  # not a multiple of the world size: the last group is short
+    # n_proj is not a multiple of the world size: the last group is short
     det, odet = B.DetectorGeometry(*g), O.DetectorGeometry(*g)
     vg = B.calculate_volume_geometry(det)
     ovg = O.calculate_volume_geometry(odet)
@@ -215,11 +222,13 @@ def _filter_shard_worker(rank, world, port, result_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_filter_sharding_matches_unsharded(tmp_path, world):
+@pytest.mark.parametrize("world,n_proj", [(2, 7), (3, 7), (8, 11)])
+def test_filter_sharding_matches_unsharded(tmp_path, world, n_proj):
+    """world 8 (the node the north star names): 61 slices -> 7 per rank + 5 more on rank 7; 11 projections = one full group of 8
+    and a short one of 3, in which ranks 3..7 have nothing to filter but still receive"""
     import torch.multiprocessing as mp
     result = str(tmp_path / "f.npy")
-    mp.spawn(_filter_shard_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+    mp.spawn(_filter_shard_worker, args=(world, _free_port(), n_proj, result), nprocs=world, join=True)
     same, finite, filtered_total = np.load(result)
     assert same == 1.0 and finite == 1.0   # bit-equal to the unsharded run; no NaN row was ever read
-    assert filtered_total == 7              # every projection was weighted and filtered exactly once across the ranks
+    assert filtered_total == n_proj         # every projection was weighted and filtered exactly once across the ranks
