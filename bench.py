@@ -325,6 +325,8 @@ def main():
                     "paris_hip_set_backproject_skip_invalid(0), reported as roofline.frac_without_skip")
     ap.add_argument("--cpu-c1", type=int, default=1, help="1 (default, N = 1 only): also time the oracle on the whole BASELINE "
                     "config-1 job (cpu_baseline_c1, a few seconds of CPU work plus ~20 s of frame synthesis)")
+    ap.add_argument("--overlap", type=int, default=1, help="deferred_boundary leg: 1 (default) = the library's default, fused launches of "
+                    "deferred calls on the ctx's second stream beside the next group's copies and filters; 0 = on the ctx stream")
     ap.add_argument("--slices", type=int, default=0, help="rehearsal only: cap the volume depth (0 = the workload's)")
     ap.add_argument("--final-gather", choices=["checksums", "slabs", "off"], default="checksums",
                     help="N > 1, after the timed region and timed separately: the job's one collective. checksums (default): "
@@ -394,6 +396,8 @@ def main():
         be.set_backproject_variant(args.variant)
     # paris::weight is held back and rides along in the load of the paris::filter call that follows: one launch for the pair
     be.set_stage_fusion(bool(args.stage_fusion))
+    if not args.overlap:
+        be.set_backproject_overlap(False)
 
     n_row, n_col, n_proj = w["n_row"], w["n_col"], w["n_proj"]
     batch = args.batch if args.batch > 0 else -(-n_proj // max(1, args.steps))
@@ -541,7 +545,7 @@ def main():
     # ---- one more step with paris_hip_set_backproject_skip_invalid(0): every tile is read and written, also those no ray
     # reaches -- the kernel's rate on exactly the algorithmic bytes. Its projections are spread over the whole circle.
     noskip_ms = None
-    if args.noskip_step and not shard:
+    if args.noskip_step and world == 1:  # (N > 1: the slabs' checksums are gathered afterwards and must be the job's)
         spread = [(j * n_proj) // batch for j in range(batch)] if batch <= n_proj else list(range(batch))
         be.set_backproject_skip_invalid(False)
         be.backproject_timing_arm(min(65536, max(1, len(spread))))

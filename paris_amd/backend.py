@@ -367,6 +367,10 @@ class Backend:
         """depth > 1: backproject() calls are snapshotted and added by one fused launch per `depth` calls (bit-identical)"""
         check(self._L.paris_hip_set_backproject_deferral(self._ctx, depth), "paris_hip_set_backproject_deferral")
 
+    def set_backproject_overlap(self, enable=True):
+        """deferred fused launches run on a second stream beside the caller's next calls (default on)"""
+        check(self._L.paris_hip_set_backproject_overlap(self._ctx, int(bool(enable))), "paris_hip_set_backproject_overlap")
+
     def flush(self):
         check(self._L.paris_hip_flush(self._ctx), "paris_hip_flush")
 

@@ -372,7 +372,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + TY - 1u) / TY;
         g.ntz = (g.v_dim_z + g.tz - 1u) / g.tz;
-        g.zchunk = order12_zchunk(g.tz, g.ntz);
+        g.zchunk = chunk_tiles(g.order, g.tz, g.ntz, 64u);
         const uint32_t blocks = static_cast<uint32_t>(grid_blocks(g));
         hipLaunchKernelGGL((bp_tile_kernel<VX, UNROLL, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, g);
     }
@@ -409,7 +409,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + 15u) / 16u;
         g.ntz = (g.v_dim_z + g.tz - 1u) / g.tz;
-        g.zchunk = order12_zchunk(g.tz, g.ntz);
+        g.zchunk = chunk_tiles(g.order, g.tz, g.ntz, 64u);
         hipLaunchKernelGGL((bp_column_state_kernel<FD>), dim3((g.v_dim_x + 255u) / 256u, g.v_dim_y), dim3(256), 0, stream, g,
                            const_cast<float*>(g.colstate));
         hipLaunchKernelGGL((bp_tile_kernel<4, UNROLL, true, FD, true>), dim3(static_cast<uint32_t>(grid_blocks(g))), dim3(256), g.lds_floats * sizeof(float), stream, g);
@@ -426,7 +426,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + TY - 1u) / TY;
         g.ntz = (g.v_dim_z + NW - 1u) / NW;
-        g.zchunk = order12_zchunk(NW, g.ntz);
+        g.zchunk = chunk_tiles(g.order, NW, g.ntz, 64u);
         const uint32_t blocks = static_cast<uint32_t>(grid_blocks(g));
         const uint32_t lds_bytes = g.lds_floats * sizeof(float);
         if(lds_bytes > 64u * 1024u) // beyond the default dynamic-LDS limit (only with a raised box budget): per launch, cheap
@@ -582,8 +582,11 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     // profiles/r02_membench.txt). The volume stream wants a compact, sliding set of concurrently touched addresses: with a y band
     // per XCD swept x -> z -> y (order 8) the set shrinks with the tile depth (bare: 6.03 / 6.25 / 6.35 / 6.5 TB/s at 16 / 8 / 4 / 2
     // slices, against 6.67 for a linear sweep and 5.9 for the XCD-contiguous order 5 at 16), while the column setup a tile pays
-    // grows as 1 / depth and the detector rows an XCD reads grow with the depth it sweeps. Planes beyond 1024^2: order 12 (order 8
-    // in chunks of 256 slices, so the detector band of a chunk stays in the XCD's L2) -- with 8-slice tiles for slabs up to 512
+    // grows as 1 / depth and the detector rows an XCD reads grow with the depth it sweeps. Planes beyond 1024^2: rounds 1-2 ran order
+    // 12 (order 8 in chunks of 256 slices, so the detector band of a chunk stays in the XCD's L2); since round 3 the y tiles are
+    // DEALT to the XCDs in pairs (order 15, bp_device.h: tile_of_block) -- once tiles no ray reaches are skipped, a band per XCD
+    // leaves the XCDs of the central bands with all the work: 0.748 -> 0.7745 of the HBM peak at 2048^3, 0.744 -> 0.756 on the
+    // 256-slice slab, 0.734 -> 0.739 at config 5 where nothing is skipped (profiles/r03_ab_tile_order.txt) -- with 8-slice tiles for slabs up to 512
     // slices (2048 x 2048 x 256: 1.447 against 1.491 ms inside bench.py's step, +3 %), with 16-slice tiles for deeper volumes
     // (2048^3: +0.2 %; 8-slice tiles are +1.1 % on one device and -0.4 % on another there; measured again after the tile prologue
     // lost its integer divisions: +0.65 % on one device, -1.2 % on the next, profiles/r02_ab_tile_depth_full_volume.txt). Planes up to 1024^2: order 5 with 8-slice
@@ -596,8 +599,8 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
         // the padding blocks of the band orders: y tiles rounded up to 8 bands, z tiles to whole chunks
         const uint32_t tz_min = std::min(tz, 8u);
         const uint64_t ntx = (v_dim_x + 63u) / 64u, nty = (v_dim_y + 3u) / 4u, ntz = (v_dim_z + tz_min - 1u) / tz_min;
-        const uint64_t zchunk = order12_zchunk(tz_min, static_cast<uint32_t>(ntz));
-        const uint64_t padded = 8ull * ((nty + 7u) / 8u) * ntx * zchunk * ((ntz + zchunk - 1u) / zchunk);
+        const uint64_t zchunk = chunk_tiles(12u, tz_min, static_cast<uint32_t>(ntz), 64u); // the deepest chunk pads most
+        const uint64_t padded = 8ull * (8u * ((nty + 63u) / 64u)) * ntx * zchunk * ((ntz + zchunk - 1u) / zchunk); // widest deal: groups of 8
         if(padded > 0x7fffff00ull)
             return PARIS_HIP_ERROR_UNSUPPORTED;
     }
@@ -657,8 +660,9 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
                       && paris_hip_volume_is_clean(ctx, d_v, static_cast<size_t>(v_dim_x) * v_dim_y * v_dim_z * sizeof(float))) ? 1u : 0u;
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
     g.tz = tz;
-    // default mapping: see the tile depth above (a y band per XCD beyond 1024^2 planes, a contiguous run of tiles per XCD below)
-    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 12u : 5u);
+    // default mapping: beyond 1024^2 planes the y tiles are dealt to the XCDs in pairs, in shallow z chunks (order 15: round 3;
+    // rounds 1-2 ran a y band per XCD there, order 12), a contiguous run of tiles per XCD below (order 5)
+    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 15u : 5u);
     g.store_sc1 = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) == 2 ? 1u : 0u;
     // 4-pixel staging needs every detector row to start 16-byte (half: 8-byte) aligned
     g.stage_vec4 = (ctx->bp_stage_vec4 != 0 && g.p_pitch % 4u == 0 && reinterpret_cast<uintptr_t>(d_p) % (4u * px) == 0)
@@ -778,7 +782,7 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
                       const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
                       const paris_region_of_interest* roi, const float* sin_phi, const float* cos_phi, float delta_s, float delta_t);
 
-int paris_hip_flush_deferred(paris_hip_ctx* ctx)
+int paris_hip_launch_deferred(paris_hip_ctx* ctx)
 {
     if(ctx != nullptr && ctx->pending_weight.active) // every observer of device state also sees a held-back weighting done
         if(int rc = paris_hip_flush_pending_weight(ctx))
@@ -789,12 +793,64 @@ int paris_hip_flush_deferred(paris_hip_ctx* ctx)
     ctx->defer_count = 0; // first: batch_impl may fall back to single launches, which must not be deferred again
     const uint32_t depth = ctx->defer_depth;
     ctx->defer_depth = 1;
-    const int rc = batch_impl(ctx, ctx->defer_ring, ctx->defer_f16, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
+    const uint32_t half = ctx->defer_half;
+    const char* ring = reinterpret_cast<const char*>(ctx->defer_ring) + static_cast<size_t>(half) * ctx->defer_slots * ctx->defer_pitch * ctx->defer_dim_y;
+    // beside the caller's next calls, on the ctx's second stream -- unless the caller wants every call complete on return, or is
+    // capturing `stream` into a graph (a fork it does not know of would leave the capture unjoined)
+    bool overlap = ctx->bp_overlap != 0 && n > 1 && !(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS);
+    if(overlap)
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if(hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+            overlap = false;
+        (void)hipGetLastError();
+    }
+    hipStream_t caller_stream = ctx->stream;
+    if(overlap)
+    {
+        if(ctx->bp_stream == nullptr)
+        {
+            PARIS_HIP_TRY(hipStreamCreateWithFlags(&ctx->bp_stream, hipStreamNonBlocking));
+            PARIS_HIP_TRY(hipEventCreateWithFlags(&ctx->bp_ring_ready, hipEventDisableTiming));
+            for(hipEvent_t& e : ctx->bp_half_done)
+                PARIS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        // everything enqueued on the caller's stream so far -- the snapshots, and whatever touched the volume before them --
+        // comes first
+        PARIS_HIP_TRY(hipEventRecord(ctx->bp_ring_ready, caller_stream));
+        PARIS_HIP_TRY(hipStreamWaitEvent(ctx->bp_stream, ctx->bp_ring_ready, 0));
+        ctx->stream = ctx->bp_stream;
+    }
+    const int rc = batch_impl(ctx, ring, ctx->defer_f16, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
                               ctx->defer_dim_y, ctx->key_v, ctx->key_dims[0], ctx->key_dims[1], ctx->key_dims[2], ctx->key_dims[3],
                               &ctx->key_det, &ctx->key_vol, ctx->key_enable_roi, &ctx->key_roi, ctx->defer_sin.data(),
                               ctx->defer_cos.data(), ctx->key_delta_s, ctx->key_delta_t);
+    ctx->stream = caller_stream;
     ctx->defer_depth = depth;
+    if(overlap)
+    {
+        PARIS_HIP_TRY(hipEventRecord(ctx->bp_half_done[half], ctx->bp_stream));
+        ctx->bp_half_busy[half] = true;
+        ctx->bp_inflight = true;
+        ctx->bp_last_half = half;
+    }
+    ctx->defer_half = half ^ 1u;
     return rc;
+}
+
+int paris_hip_flush_deferred(paris_hip_ctx* ctx)
+{
+    if(int rc = paris_hip_launch_deferred(ctx))
+        return rc;
+    if(ctx != nullptr && ctx->bp_inflight)
+    {
+        // join: what the caller enqueues on its stream from here on comes after every fused launch (launches on bp_stream are
+        // in order, so the last one's event covers all)
+        PARIS_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->bp_half_done[ctx->bp_last_half], 0));
+        ctx->bp_inflight = false;
+        ctx->bp_half_busy[0] = ctx->bp_half_busy[1] = false; // both halves' launches precede that event
+    }
+    return PARIS_HIP_SUCCESS;
 }
 
 static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, uint32_t p_dim_x, uint32_t p_dim_y, float* d_v,
@@ -833,7 +889,7 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
             }
             ctx->defer_pitch = (static_cast<size_t>(p_dim_x) * px + 255u) / 256u * 256u;
             ctx->defer_f16 = f16;
-            PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->defer_ring), ctx->defer_pitch * p_dim_y * ctx->defer_depth));
+            PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->defer_ring), 2u * ctx->defer_pitch * p_dim_y * ctx->defer_depth)); // two halves
             ctx->defer_dim_x = p_dim_x;
             ctx->defer_dim_y = p_dim_y;
             ctx->defer_slots = ctx->defer_depth;
@@ -849,7 +905,14 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
         ctx->defer_sin.assign(ctx->defer_depth, 0.f);
         ctx->defer_cos.assign(ctx->defer_depth, 0.f);
     }
-    char* slot = reinterpret_cast<char*>(ctx->defer_ring) + ctx->defer_pitch * p_dim_y * ctx->defer_count;
+    const uint32_t half = ctx->defer_half;
+    if(ctx->defer_count == 0 && ctx->bp_half_busy[half])
+    {
+        // the fused launch that read this half of the ring (two groups ago) must be done before the half is written again
+        PARIS_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->bp_half_done[half], 0));
+        ctx->bp_half_busy[half] = false;
+    }
+    char* slot = reinterpret_cast<char*>(ctx->defer_ring) + ctx->defer_pitch * p_dim_y * (static_cast<size_t>(half) * ctx->defer_slots + ctx->defer_count);
     PARIS_HIP_TRY(hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * px, p_dim_y,
                                    hipMemcpyDeviceToDevice, ctx->stream));
     if(int rc = paris_hip_note_projection_use(ctx, d_p, p_pitch * p_dim_y)) // the snapshot copy is the last reader of the caller's buffer
@@ -857,7 +920,12 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
     ctx->defer_sin[ctx->defer_count] = sin_phi;
     ctx->defer_cos[ctx->defer_count] = cos_phi;
     if(++ctx->defer_count == ctx->defer_depth)
-        return paris_hip_flush_deferred(ctx);
+    {
+        if(int rc = paris_hip_launch_deferred(ctx)) // no join: the caller's next calls run beside the launch
+            return rc;
+        if(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS)
+            return paris_hip_flush_deferred(ctx);
+    }
     return paris_hip_finish(ctx);
 }
 
@@ -868,6 +936,16 @@ extern "C" int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t d
     if(int rc = paris_hip_flush_deferred(ctx))
         return rc;
     ctx->defer_depth = depth;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_set_backproject_overlap(paris_hip_ctx* ctx, int enable)
+{
+    if(ctx == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
+    ctx->bp_overlap = enable ? 1 : 0;
     return PARIS_HIP_SUCCESS;
 }
 
@@ -1105,7 +1183,7 @@ extern "C" int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, in
 {
     if(int rc = paris_hip_flush_deferred(ctx))
         return rc;
-    if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5 || order == 8 || order == 9 || order == 12) || nontemporal < -1 || nontemporal > 2)
+    if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5 || order == 8 || order == 9 || order == 12 || (order >= 14 && order <= 17)) || nontemporal < -1 || nontemporal > 2)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_order = order;
     ctx->bp_nt = nontemporal; // < 0: automatic (by slab size)

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -136,6 +137,13 @@ namespace
         return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
     }
 
+    // orders 14 .. 17: y tiles are dealt to the XCDs in groups of 1, 2, 4, 8; an XCD's share of the y tiles, whole groups
+    __host__ __device__ inline uint32_t dealt_band(uint32_t nty, uint32_t order)
+    {
+        const uint32_t grp = 1u << (order - 14u);
+        return grp * ((nty + 8u * grp - 1u) / (8u * grp));
+    }
+
     // 1-D grid size for the tile mapping in g.order (tile_of_block rejects the padding blocks)
     // (64-bit: the padded count of a band order can exceed the tile count by the band and chunk rounding; fill_params has checked
     // that the worst case over kernels and orders fits a 1-D grid)
@@ -148,14 +156,22 @@ namespace
             return 8ull * ((g.nty + 7u) / 8u) * g.ntx * g.ntz;
         if(g.order == 12u)
             return 8ull * ((g.nty + 7u) / 8u) * g.ntx * g.zchunk * ((g.ntz + g.zchunk - 1u) / g.zchunk);
+        if(g.order >= 14u)
+            return 8ull * dealt_band(g.nty, g.order) * g.ntx * g.zchunk * ((g.ntz + g.zchunk - 1u) / g.zchunk);
         return total;
     }
 
-    // z tiles per chunk of order 12: chunks of 256 slices, never more z tiles than the volume has (a shallow slab would otherwise
-    // launch up to 32 times as many workgroups as it has tiles, all but a few leaving at once: ADVICE r02)
-    inline uint32_t order12_zchunk(uint32_t tz, uint32_t ntz)
+    // z tiles per chunk of the chunked orders, never more z tiles than the volume has (a shallow slab would otherwise launch up
+    // to 32 times as many workgroups as it has tiles, all but a few leaving at once: ADVICE r02). Order 12 (a y BAND per XCD)
+    // wants chunks of 256 slices: the detector band of a chunk then stays in the XCD's L2. The dealt orders 14 .. 17 (all XCDs
+    // on adjacent y tiles) want shallow chunks: 2048^3 with order 15, same device, single-projection kernel 0.7673 / 0.7706 /
+    // 0.7745 / 0.7726 of the HBM peak for chunks of 256 / 128 / 64 / 32 slices, fused kernel 1699 / 1719 / 1726 / 1740 GVox/s
+    // (profiles/r03_ab_tile_order.txt): `deep` slices for them (64 for the tile kernel, 32 = one tile for the fused kernel).
+    inline uint32_t chunk_tiles(uint32_t order, uint32_t tz, uint32_t ntz, uint32_t deep)
     {
-        return std::min(std::max(1u, 256u / std::max(1u, tz)), std::max(1u, ntz));
+        static const uint32_t forced = [] { const char* e = std::getenv("PARIS_BP_ZCHUNK_SLICES"); return e ? static_cast<uint32_t>(std::atoi(e)) : 0u; }(); // experiments
+        const uint32_t slices = forced ? forced : (order >= 14u ? deep : 256u);
+        return std::min(std::max(1u, slices / std::max(1u, tz)), std::max(1u, ntz));
     }
 
     // ext-vector twins of float/float2/float4 for the nontemporal builtins
@@ -199,6 +215,7 @@ namespace
     //   8: XCD k owns a band of y tiles; x fastest, then z, then y inside the band
     //   9: XCD k owns a band of y tiles; x fastest, then y, then z inside the band
     //  12: order 8 chunk by chunk of 256 slices (deep volumes)
+    //  14: order 12 with y tiles dealt round-robin to the XCDs (XCD k owns y tiles k, k + 8, ...); 15, 16, 17: dealt in groups of 2, 4, 8
     __device__ __forceinline__ bool tile_of_block(const BpParams& g, uint32_t b, uint32_t& bx, uint32_t& by, uint32_t& bz)
     {
         const uint32_t total = g.ntx * g.nty * g.ntz;
@@ -225,6 +242,31 @@ namespace
             const uint32_t yb = r / g.ntz;
             by = xcd * band + yb;
             return yb < band && by < g.nty;
+        }
+        if(g.order >= 14u)
+        {
+            // order 12 with the y tiles DEALT to the XCDs instead of banded. Order 14: XCD k owns y tiles k, k + 8, k + 16, ...;
+            // order 15 deals pairs (XCD k owns y tiles 2k, 2k + 1, 2k + 16, 2k + 17, ...), 16 and 17 groups of 4 and 8. x runs
+            // fastest, then the z tile inside the chunk, then the XCD's next y tile, then the chunk. Every XCD sees an even sample
+            // of the plane, so tiles no ray reaches (the grid's corners on the source side, whole y bands at some angles) thin out
+            // every XCD's share alike -- with banded orders the XCDs of the central bands, which have nothing to skip, finish last
+            // and the launch waits for them (2048^3, same device: 0.748 -> 0.763-0.766 of the HBM peak for the single-projection
+            // kernel, 1.63 -> 1.70-1.72 TVox/s for the fused one, profiles/r03_ab_tile_order.txt). The eight XCDs work on adjacent
+            // y tiles at any time: a compact window. Pairs keep the banded order's rate where nothing is skipped (0.719 against
+            // 0.711 for single tiles) at the same rate with the skip.
+            const uint32_t band = dealt_band(g.nty, g.order);
+            const uint32_t zchunk = g.zchunk;
+            const uint32_t xcd = b % 8u;
+            uint32_t r = b / 8u;
+            bx = r % g.ntx;
+            r /= g.ntx;
+            const uint32_t zl = r % zchunk;
+            r /= zchunk;
+            const uint32_t yb = r % band;
+            bz = (r / band) * zchunk + zl;
+            const uint32_t grp = 1u << (g.order - 14u);
+            by = (yb / grp) * (8u * grp) + xcd * grp + yb % grp;
+            return bz < g.ntz && by < g.nty;
         }
         if(g.order == 12u)
         {

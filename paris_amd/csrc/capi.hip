@@ -195,6 +195,15 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
         }
         ctx->defer_count = 0;
     }
+    if(ctx->bp_stream != nullptr)
+    {
+        (void)hipStreamSynchronize(ctx->bp_stream); // fused launches the caller never joined (it never looked at the volume again)
+        (void)hipEventDestroy(ctx->bp_ring_ready);
+        for(hipEvent_t e : ctx->bp_half_done)
+            (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(ctx->bp_stream);
+        ctx->bp_stream = nullptr;
+    }
     for(auto& kv : ctx->plans)
     {
         (void)hipFree(kv.second.d_twiddle);
@@ -534,6 +543,9 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
         PARIS_HIP_TRY(hipFree(d_ptr));
         return PARIS_HIP_SUCCESS;
     }
+    if(ctx->defer_count == 0 && ctx->bp_inflight)
+        if(int rc = paris_hip_flush_deferred(ctx)) // nothing pending, but a fused launch may still run on the second stream: join
+            return rc;
     if(ctx->defer_count != 0)
     {
         // pending projections write into key_v: run them first if that volume lives in the allocation being freed
@@ -541,7 +553,7 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
         size_t size = 0;
         const bool known = hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, d_ptr) == hipSuccess;
         const char* kv = reinterpret_cast<const char*>(ctx->key_v);
-        if(!known || (kv >= static_cast<const char*>(base) && kv < static_cast<const char*>(base) + size))
+        if(!known || (kv >= static_cast<const char*>(base) && kv < static_cast<const char*>(base) + size) || ctx->bp_inflight)
             if(int rc = paris_hip_flush_deferred(ctx))
                 return rc;
         (void)hipGetLastError();

@@ -283,8 +283,14 @@ namespace
             {
                 const uint32_t idx = o + j * NO;
                 const uint32_t at = idx < a.dim_x ? idx : 0u;
+#ifdef PARIS_FILTER_TIMING_NO_MEMORY // wrong results: prices the arithmetic alone (tools/README.md)
+                xs[j] = static_cast<float>(at) * 1e-3f;
+                ys[j] = static_cast<float>(at + blockIdx.x) * 1e-3f;
+                (void)pb_safe;
+#else
                 xs[j] = pa[at];
                 ys[j] = pb_safe[at];
+#endif
             }
 #pragma unroll
             for(uint32_t j = 0; j < EF; ++j)
@@ -307,6 +313,20 @@ namespace
                 }
                 v[j] = make_float2(x, y);
             }
+#ifdef PARIS_FILTER_TIMING_NO_COMPUTE // wrong results: prices the loads (with the weighting) and the stores alone
+#pragma unroll
+            for(uint32_t j = 0; j < JN; ++j)
+            {
+                const uint32_t idx = o + j * NO;
+                if(idx < a.dim_x)
+                {
+                    pa[idx] = v[j].x;
+                    if(has_b)
+                        pb[idx] = v[j].y;
+                }
+            }
+            continue;
+#endif
             dft_forward<RF, HALF && (RF > 0)>(v);
 #pragma unroll
             for(uint32_t i = 0; i < EF; ++i)
@@ -318,6 +338,9 @@ namespace
                 fx[lds_pad(q * NO + o)] = x;
             }
         }
+#ifdef PARIS_FILTER_TIMING_NO_COMPUTE
+        return;
+#endif
         __syncthreads();
 
         // ---- forward middle passes: radix 16 on blocks of B = 16^(NPASS - pass)
@@ -437,8 +460,14 @@ namespace
                     }
                     else
                     {
+#ifdef PARIS_FILTER_TIMING_NO_MEMORY
+                        if(v[j].x == 123456.789f) // never: keeps the arithmetic alive without the stores
+#endif
                         pa[idx] = v[j].x * inv_n;
                         if(has_b)
+#ifdef PARIS_FILTER_TIMING_NO_MEMORY
+                            if(v[j].y == 123456.789f)
+#endif
                             pb[idx] = v[j].y * inv_n;
                     }
                 }

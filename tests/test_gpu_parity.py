@@ -1329,6 +1329,59 @@ def test_full_size_2048_cube_properties(oracle):
         del fused, full
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_deferred_groups_on_the_second_stream(oracle, kat_golden, overlap):
+    """paris_hip_set_backproject_overlap: the fused launch of a full ring runs on the ctx's second stream while the caller keeps
+    enqueuing the next group's copies on the ctx stream. 42 projections through a ring of 4 -- ten full groups, so both halves
+    of the ring are rewritten many times while launches that read them may still be running, and a last partial group -- from
+    ONE device buffer that is overwritten for every call, nothing synchronising in between; then an observer (volume copy) and
+    more calls. Bit-equal to the oracle either way."""
+    import torch
+    det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
+    vg, ovg = B.calculate_volume_geometry(det), oracle.calculate_volume_geometry(odet)
+    filtered = kat_golden["filtered"]
+    n = 42
+    frames = [np.ascontiguousarray(filtered[i % 8] * np.float32(1.0 + 0.03125 * (i // 8))) for i in range(n)]
+    idx = [(5 * i) % 29 for i in range(n)]  # any angles
+    want = np.zeros((61, 67, 67), np.float32)
+    checkpoints = {}
+    for i in range(n):
+        s, c, ds, dt = oracle.backproject_constants(odet, idx[i])
+        oracle.backproject(want, frames[i], 0, odet, ovg, s, c, ds, dt)
+        if i in (16, n - 1):
+            checkpoints[i] = want.copy()
+    with B.Backend(0, synchronous=False) as abe:
+        L, ctx = abe._L, abe._ctx
+        abe.set_backproject_overlap(overlap)
+        pinned = [torch.from_numpy(f).pin_memory() for f in frames]
+        d_p = abe.make_projection_device(64, 48)
+        d_v = abe.make_volume_device(67, 67, 61)
+        abe.set_backproject_deferral(4)
+        for i in range(n):
+            assert L.paris_hip_memcpy_projection_h2d(ctx, d_p.ptr, d_p.pitch, pinned[i].data_ptr(), 64 * 4, 64, 48) == 0
+            d_p.idx = idx[i]
+            B.backproject(abe, d_p, d_v, 0, det, vg, False, False, None)
+            if i == 16:  # an observer in mid-stream: one projection pending, a launch possibly still running on the other stream
+                assert_bit_equal(volume_to_host(abe, d_v), checkpoints[16])
+        assert_bit_equal(volume_to_host(abe, d_v), checkpoints[n - 1])
+        # freeing the volume with work pending / in flight must be safe (and a new volume may land on the same address)
+        for i in range(6):
+            assert L.paris_hip_memcpy_projection_h2d(ctx, d_p.ptr, d_p.pitch, pinned[i].data_ptr(), 64 * 4, 64, 48) == 0
+            d_p.idx = idx[i]
+            B.backproject(abe, d_p, d_v, 0, det, vg, False, False, None)
+        abe.free(d_v)
+        d_w = abe.make_volume_device(67, 67, 61)
+        for i in range(5):
+            assert L.paris_hip_memcpy_projection_h2d(ctx, d_p.ptr, d_p.pitch, pinned[i].data_ptr(), 64 * 4, 64, 48) == 0
+            d_p.idx = idx[i]
+            B.backproject(abe, d_p, d_w, 0, det, vg, False, False, None)
+        want5 = np.zeros((61, 67, 67), np.float32)
+        for i in range(5):
+            s, c, ds, dt = oracle.backproject_constants(odet, idx[i])
+            oracle.backproject(want5, frames[i], 0, odet, ovg, s, c, ds, dt)
+        assert_bit_equal(volume_to_host(abe, d_w), want5)
+
+
 def device_view(torch, v, dev):
     """a torch tensor over a library-allocated volume (z, y, x): the same memory, no copy"""
     class _Mem:
