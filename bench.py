@@ -325,8 +325,11 @@ def main():
                     "paris_hip_set_backproject_skip_invalid(0), reported as roofline.frac_without_skip")
     ap.add_argument("--cpu-c1", type=int, default=1, help="1 (default, N = 1 only): also time the oracle on the whole BASELINE "
                     "config-1 job (cpu_baseline_c1, a few seconds of CPU work plus ~20 s of frame synthesis)")
-    ap.add_argument("--overlap", type=int, default=1, help="deferred_boundary leg: 1 (default) = the library's default, fused launches of "
-                    "deferred calls on the ctx's second stream beside the next group's copies and filters; 0 = on the ctx stream")
+    ap.add_argument("--overlap", type=int, default=0, help="deferred_boundary leg: 1 = fused launches of deferred calls on the ctx's "
+                    "second stream beside the next group's copies and filters (paris_hip_set_backproject_overlap); 0 (default, the "
+                    "library's default) = on the ctx stream")
+    ap.add_argument("--spread", type=int, default=0, help="1: with a partial job (--batch), the timed projections are spread evenly "
+                    "over the circle instead of taken from its start (counter runs: a few launches that sample every angle)")
     ap.add_argument("--slices", type=int, default=0, help="rehearsal only: cap the volume depth (0 = the workload's)")
     ap.add_argument("--final-gather", choices=["checksums", "slabs", "off"], default="checksums",
                     help="N > 1, after the timed region and timed separately: the job's one collective. checksums (default): "
@@ -396,8 +399,7 @@ def main():
         be.set_backproject_variant(args.variant)
     # paris::weight is held back and rides along in the load of the paris::filter call that follows: one launch for the pair
     be.set_stage_fusion(bool(args.stage_fusion))
-    if not args.overlap:
-        be.set_backproject_overlap(False)
+    be.set_backproject_overlap(bool(args.overlap))
 
     n_row, n_col, n_proj = w["n_row"], w["n_col"], w["n_proj"]
     batch = args.batch if args.batch > 0 else -(-n_proj // max(1, args.steps))
@@ -529,6 +531,9 @@ def main():
     if graphs is not None:
         for g in graphs:
             g.replay()
+    elif args.spread and timed_launches < n_proj:
+        for s in range(args.steps):
+            step(0, indices=[((s * batch + j) * n_proj) // timed_launches for j in range(batch)])
     else:
         for s in range(args.steps):
             step(s * batch)
@@ -606,12 +611,14 @@ def main():
         td0 = time.perf_counter()
         for first in starts:
             step(first, fb)
+        td_host = time.perf_counter() - td0  # the host's share: every call has returned, the GPU may still be working
         be.flush()
         torch.cuda.synchronize()
         barrier()
         td = max_over_ranks(time.perf_counter() - td0)
         be.set_backproject_deferral(1)
         fused["deferred_seconds"] = td
+        fused["deferred_host_seconds"] = td_host
         fused["deferred_projections"] = len(starts) * fb
 
     # ---- the job's one collective (north star: "no RCCL collective needed beyond a final gather"), timed on its own
@@ -740,6 +747,10 @@ def main():
                             % (fb, fb),
                     "value": voxels_all * fused["deferred_projections"] / fused["deferred_seconds"] / 1e9,
                     "unit": "GVoxel-updates/s",
+                    # how long the calls themselves took to return (Python + ctypes + HIP enqueue): close to 1 = the leg is bound
+                    # by the host loop, not by the GPU
+                    "host_enqueue_share": fused["deferred_host_seconds"] / fused["deferred_seconds"],
+                    "us_per_projection": fused["deferred_seconds"] / fused["deferred_projections"] * 1e6,
                 }
         if gather is not None:
             out["final_gather"] = gather

@@ -288,12 +288,13 @@ int paris_hip_backproject_batch_f16(paris_hip_ctx* ctx, const uint16_t* d_p, siz
  * (src/main.cpp:98-105) runs at the fused kernel's rate. */
 int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t depth);
 int paris_hip_flush(paris_hip_ctx* ctx);
-/* Where the fused launch of a full group runs: with enable != 0 (the default) on a second stream of the ctx, ordered behind the
+/* Where the fused launch of a full group runs: with enable != 0 on a second stream of the ctx, ordered behind the
  * group's snapshot copies, so that the uploads, weightings and filters of the NEXT group -- which the caller keeps enqueuing on
  * the ctx stream -- execute beside it instead of behind it (what small volumes need: a 256^3 launch of 16 projections takes about
  * as long as the sixteen copy + filter launches of the next group). Every entry point that flushes (see above) also makes the ctx
  * stream wait for the launches on the second stream, so the caller sees one stream's worth of ordering. Not used under
- * PARIS_HIP_CTX_SYNCHRONOUS or while the ctx stream is being captured into a graph. Results never depend on it. */
+ * PARIS_HIP_CTX_SYNCHRONOUS or while the ctx stream is being captured into a graph. Results never depend on it. Off by default: on
+ * MI355X the fused kernel leaves the other stream's small kernels no room and the switch measured slower. */
 int paris_hip_set_backproject_overlap(paris_hip_ctx* ctx, int enable);
 
 /* ---- stage wrappers and geometry (host code of the hot path) ----------------------------------------

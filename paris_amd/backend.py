@@ -368,7 +368,7 @@ class Backend:
         check(self._L.paris_hip_set_backproject_deferral(self._ctx, depth), "paris_hip_set_backproject_deferral")
 
     def set_backproject_overlap(self, enable=True):
-        """deferred fused launches run on a second stream beside the caller's next calls (default on)"""
+        """deferred fused launches run on a second stream beside the caller's next calls (default off: measured slower)"""
         check(self._L.paris_hip_set_backproject_overlap(self._ctx, int(bool(enable))), "paris_hip_set_backproject_overlap")
 
     def flush(self):

@@ -913,8 +913,11 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
         ctx->bp_half_busy[half] = false;
     }
     char* slot = reinterpret_cast<char*>(ctx->defer_ring) + ctx->defer_pitch * p_dim_y * (static_cast<size_t>(half) * ctx->defer_slots + ctx->defer_count);
-    PARIS_HIP_TRY(hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * px, p_dim_y,
-                                   hipMemcpyDeviceToDevice, ctx->stream));
+    if(p_pitch == ctx->defer_pitch) // rows as far apart as the ring's: one linear copy (the padding travels along)
+        PARIS_HIP_TRY(hipMemcpyAsync(slot, d_p, p_pitch * (p_dim_y - 1u) + static_cast<size_t>(p_dim_x) * px, hipMemcpyDeviceToDevice, ctx->stream));
+    else
+        PARIS_HIP_TRY(hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * px, p_dim_y,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
     if(int rc = paris_hip_note_projection_use(ctx, d_p, p_pitch * p_dim_y)) // the snapshot copy is the last reader of the caller's buffer
         return rc;
     ctx->defer_sin[ctx->defer_count] = sin_phi;
