@@ -70,8 +70,11 @@ namespace
         st[2u * plane + at] = c.u;
     }
 
+#ifndef PARIS_TILE_MIN_WAVES
+#define PARIS_TILE_MIN_WAVES 1
+#endif
     template <int VX, int UNROLL, bool NT, bool FD, bool PRE = false>
-    __global__ void __launch_bounds__(256) bp_tile_kernel(const BpParams g)
+    __global__ void __launch_bounds__(256, PARIS_TILE_MIN_WAVES) bp_tile_kernel(const BpParams g)
     {
         extern __shared__ __attribute__((aligned(16))) float lds[];
 

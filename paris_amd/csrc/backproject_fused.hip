@@ -26,19 +26,15 @@ namespace
     // 128 pixels wide -- the 64-column tile at magnifications up to about 2 -- take it, wider ones keep their own stride
     constexpr int FIXED_STRIDE = 132;
 
-    // NW: waves per workgroup (4, or 8 for the one-column x 32-slice shape: a tile of 64 x 8 columns shares ONE staged box per
-    // projection between twice as many lanes -- the box of a 64 x 8 x 32 tile is barely larger than that of 64 x 4 x 32 (its rows
-    // are set by the 32 slices, its width by the 64 columns), so the staging instructions per voxel-update and the L2 -> LDS
-    // bytes halve)
-    template <int VX, int TZ, bool NT, bool FD, int NW = 4>
-    __global__ void __launch_bounds__(NW * 64, PARIS_FUSED_WAVES + (VX == 2 ? 1 : VX == 1 ? (TZ == 32 ? 1 : 4) : 0) + (TZ == 8 ? 1 : 0)) bp_fused_kernel(const FusedParams fp)
+    template <int VX, int TZ, bool NT, bool FD>
+    __global__ void __launch_bounds__(256, PARIS_FUSED_WAVES + (VX == 2 ? 1 : VX == 1 ? (TZ == 32 ? 1 : 4) : 0) + (TZ == 8 ? 1 : 0)) bp_fused_kernel(const FusedParams fp)
     {
         extern __shared__ __attribute__((aligned(16))) float lds[];
         BpParams g = fp.g;
         using vec = typename vec_of<VX>::type;
         constexpr uint32_t XL = 64u / VX; // lanes along x per wave
         constexpr uint32_t RW = VX;       // volume rows per wave
-        constexpr uint32_t TY = static_cast<uint32_t>(NW) * RW;
+        constexpr uint32_t TY = 4u * RW;
 
         const uint32_t tid = threadIdx.x;
         const uint32_t lane = tid & 63u;
@@ -91,7 +87,7 @@ namespace
 #ifdef PARIS_TIMING_ONLY_STAGE_ONCE // wrong results: prices the per-projection staging (tools/README.md)
             if(p == 0u)
 #endif
-            stage_box(g, box, lds, wave, static_cast<uint32_t>(NW), lane);
+            stage_box(g, box, lds, wave, 4u, lane);
 #ifdef PARIS_TIMING_ONLY_NO_BARRIERS
             if(p == 0u)
 #endif
@@ -184,40 +180,37 @@ namespace
                 store_voxels<VX, NT>(vp + z * slice, acc[z], g.store_sc1 != 0u);
     }
 
-    template <int VX, int TZ, bool NT, bool FD, int NW = 4>
+    template <int VX, int TZ, bool NT, bool FD>
     void launch_fused(FusedParams& fp, hipStream_t stream)
     {
         BpParams& g = fp.g;
         g.tz = TZ;
         g.ntx = (g.v_dim_x + 63u) / 64u;
-        g.nty = (g.v_dim_y + NW * VX - 1u) / (NW * VX);
+        g.nty = (g.v_dim_y + 4u * VX - 1u) / (4u * VX);
         g.ntz = (g.v_dim_z + TZ - 1u) / TZ;
         g.zchunk = chunk_tiles(g.order, TZ, g.ntz, 32u);
         const uint32_t blocks = static_cast<uint32_t>(grid_blocks(g));
-        hipLaunchKernelGGL((bp_fused_kernel<VX, TZ, NT, FD, NW>), dim3(blocks), dim3(NW * 64), g.lds_floats * sizeof(float), stream, fp);
+        hipLaunchKernelGGL((bp_fused_kernel<VX, TZ, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, fp);
     }
 
-    template <int VX, int TZ, int NW = 4>
+    template <int VX, int TZ>
     void launch_fused_flags(FusedParams& fp, bool nt, bool fd, hipStream_t stream)
     {
         if(nt && fd)
-            launch_fused<VX, TZ, true, true, NW>(fp, stream);
+            launch_fused<VX, TZ, true, true>(fp, stream);
         else if(nt)
-            launch_fused<VX, TZ, true, false, NW>(fp, stream);
+            launch_fused<VX, TZ, true, false>(fp, stream);
         else if(fd)
-            launch_fused<VX, TZ, false, true, NW>(fp, stream);
+            launch_fused<VX, TZ, false, true>(fp, stream);
         else
-            launch_fused<VX, TZ, false, false, NW>(fp, stream);
+            launch_fused<VX, TZ, false, false>(fp, stream);
     }
 }
 
 void paris_hip_bp_launch_fused(const void* fused_params, int vx, int tz, bool nt, bool fd, hipStream_t stream)
 {
     FusedParams fp = *static_cast<const FusedParams*>(fused_params);
-    static const int wide = [] { const char* e = std::getenv("PARIS_FUSED_WIDE"); return e ? std::atoi(e) : 0; }(); // experiment
-    if(vx == 1 && tz == 32 && wide) // 8 waves: a 64 x 8 x 32 tile
-        launch_fused_flags<1, 32, 8>(fp, nt, fd, stream);
-    else if(vx == 1 && tz == 32) // one column per lane, 32 slices deep: half the column setups per voxel-update of <2, 16>
+    if(vx == 1 && tz == 32) // one column per lane, 32 slices deep: half the column setups per voxel-update of <2, 16>
         launch_fused_flags<1, 32>(fp, nt, fd, stream);
     else if(vx == 1) // tz 8 is not built for this width
         launch_fused_flags<1, 16>(fp, nt, fd, stream);
