@@ -58,7 +58,7 @@ namespace
 
         const size_t slice = static_cast<size_t>(g.v_dim_x) * g.v_dim_y;
         float* vp = g.vol + (static_cast<size_t>(m0) * g.v_dim_y + l) * g.v_dim_x + k;
-        vec acc[TZ];
+        vec acc[TZ] = {};
 #pragma unroll
         for(int z = 0; z < TZ; ++z)
             if(active && static_cast<uint32_t>(z) < mcount)
@@ -92,14 +92,17 @@ namespace
             if(p == 0u)
 #endif
             __syncthreads();
-            if(active)
+            // EVERY lane takes part: a lane beyond the volume's edge works on the nearest column inside it and its sums are never
+            // stored. A per-lane `if(active)` around the body would be a divergent region, in which the compiler must keep the old
+            // sums alive for the lanes that sit it out; with only wave-uniform branches left (and the uniform regions not
+            // structurized: Makefile) the TZ x VX sums are added in place -- 106 VGPRs and no scratch against 128 and moves.
             {
                 Column col[VX];
                 bool all_fast = true, all_inside = true, all_none = true;
 #pragma unroll
                 for(int j = 0; j < VX; ++j)
                 {
-                    col[j] = make_column<FD>(g, box, g.k_off + k + j, g.l_off + l, z_first, z_last);
+                    col[j] = make_column<FD>(g, box, g.k_off + min(k + j, k1), g.l_off + min(l, l1), z_first, z_last);
                     all_fast = all_fast && col[j].fast;
                     all_inside = all_inside && col[j].inside;
                     all_none = all_none && col[j].none;
