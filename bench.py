@@ -244,7 +244,8 @@ def fused_report(fused, fb, f16, voxels_rank, voxels_all, n_row, n_col, per_laun
     hbm_gbps = ((8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col * fb) / (fused["kernel_ms"] * 1e-3) / 1e9
                 if fused["kernel_ms"] > 0 else 0.0)
     rep = {
-        "what": "the same per-projection copy + weight + filter, but one fused launch adds %d projections "
+        "what": "the same per-projection copy, then weight + filter of the group's frames (one launch for all of them unless "
+                "--filter-batch 0) and one fused launch that adds %d projections "
                 "(paris_hip_backproject_batch; bit-identical volume); not the headline because the plugin boundary is one "
                 "projection per call" % fb,
         "value": voxels_all * fb * fused["steps"] / fused["seconds"] / 1e9,
@@ -325,6 +326,8 @@ def main():
                     "paris_hip_set_backproject_skip_invalid(0), reported as roofline.frac_without_skip")
     ap.add_argument("--cpu-c1", type=int, default=1, help="1 (default, N = 1 only): also time the oracle on the whole BASELINE "
                     "config-1 job (cpu_baseline_c1, a few seconds of CPU work plus ~20 s of frame synthesis)")
+    ap.add_argument("--filter-batch", type=int, default=1, help="fused_extension leg: 1 (default) = the group's frames are weighted and "
+                    "filtered by one launch (paris_hip_stage_weight_filter_batch), 0 = one launch per frame")
     ap.add_argument("--overlap", type=int, default=0, help="deferred_boundary leg: 1 = fused launches of deferred calls on the ctx's "
                     "second stream beside the next group's copies and filters (paris_hip_set_backproject_overlap); 0 (default, the "
                     "library's default) = on the ctx stream")
@@ -573,11 +576,17 @@ def main():
             idx = [(first_idx + b) % n_proj for b in range(fb)]
             for b in range(fb):
                 work[b, band].copy_(raw[b, band], non_blocking=True)
+                if args.filter_batch:
+                    continue
                 if f16:
                     B.weight_filter_rows(be, projs[b], det, band_first, band_count, halves[b].data_ptr(), n_row * 2)
                 else:
                     B.weight_rows(be, projs[b], det, band_first, band_count)
                     B.filter_rows(be, projs[b], det, band_first, band_count)
+            if args.filter_batch:
+                # the group's frames weighted and filtered by ONE launch (paris_hip_stage_weight_filter_batch; bit-identical)
+                B.weight_filter_batch(be, work.data_ptr(), pitch, stride, fb, n_row, n_col, det, band_first, band_count,
+                                      halves.data_ptr() if f16 else None, n_row * 2 if f16 else 0, n_row * n_col * 2 if f16 else 0)
             if f16:
                 be.backproject_batch_f16(halves.data_ptr(), n_row * 2, n_row * n_col * 2, fb, n_row, n_col, d_vol, z_first, det,
                                          vol_geo, roi is not None, roi, [sc[i][0] for i in idx], [sc[i][1] for i in idx], 0.0, 0.0)

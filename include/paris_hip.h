@@ -224,6 +224,15 @@ int paris_hip_weight_filter_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, u
                                  float l_px_row, float l_px_col, const float* d_k, uint32_t filter_size, uint16_t* d_half,
                                  size_t half_pitch);
 
+/* Extension: the same for a GROUP of n_frames projections in one launch: frame f starts frame_stride bytes behind frame f - 1
+ * (>= pitch * dim_y: frames must not overlap; d_half likewise, half_frame_stride bytes apart). For a driver that holds a group of
+ * uploaded frames before a paris_hip_backproject_batch: with small detectors a launch per frame is mostly launch latency.
+ * Bit-identical to n_frames paris_hip_weight_filter_rows calls. n_frames <= 65535. */
+int paris_hip_weight_filter_batch(paris_hip_ctx* ctx, float* d_p, size_t pitch, size_t frame_stride, uint32_t n_frames, uint32_t dim_x,
+                                  uint32_t dim_y, uint32_t row_first, uint32_t row_count, float h_min, float v_min, float d_sd,
+                                  float l_px_row, float l_px_col, const float* d_k, uint32_t filter_size, uint16_t* d_half,
+                                  size_t half_pitch, size_t half_frame_stride);
+
 /* ---- backprojection: backend::backproject (src/openmp/backprojection.cpp:156-199,
  *      src/cuda/backprojection.cu:133-243) ---------------------------------------------------------- */
 /* Adds one filtered projection into the (sub)volume d_v of v_dim_x*v_dim_y*v_dim_z voxels whose first
@@ -325,6 +334,12 @@ int paris_hip_stage_filter_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, ui
 int paris_hip_stage_weight_filter_rows(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
                                        uint32_t row_first, uint32_t row_count, const paris_detector_geometry* det_geo,
                                        uint16_t* d_half, size_t half_pitch);
+/* Extension: paris_hip_stage_weight_filter_rows for a group of n_frames projections frame_stride bytes apart in one launch
+ * (paris_hip_weight_filter_batch with the wrappers' constants and cached K; narrow detectors run frame by frame: same result). */
+int paris_hip_stage_weight_filter_batch(paris_hip_ctx* ctx, float* d_p, size_t pitch, size_t frame_stride, uint32_t n_frames,
+                                        uint32_t dim_x, uint32_t dim_y, uint32_t row_first, uint32_t row_count,
+                                        const paris_detector_geometry* det_geo, uint16_t* d_half, size_t half_pitch,
+                                        size_t half_frame_stride);
 /* Extension (f4; no reference counterpart): the detector rows [*row_first, *row_first +
  * *row_count) that backprojecting into the slab (v_dim_*, v_offset, optional ROI; arguments as paris_hip_backproject)
  * can read for ANY projection angle. Rows outside the band never contribute to the slab, so a driver may upload,

@@ -94,6 +94,8 @@ SIGNATURES = {
     "paris_hip_volume_mark_dirty": (C.c_int, [_vp, _vp, _sz]),
     "paris_hip_volume_mark_clean": (C.c_int, [_vp, _vp, _sz]),
     "paris_hip_weight_filter_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _f, _f, _f, _f, _f, _vp, _u32, _vp, _sz]),
+    "paris_hip_weight_filter_batch": (C.c_int, [_vp, _vp, _sz, _sz, _u32, _u32, _u32, _u32, _u32, _f, _f, _f, _f, _f, _vp, _u32, _vp, _sz, _sz]),
+    "paris_hip_stage_weight_filter_batch": (C.c_int, [_vp, _vp, _sz, _sz, _u32, _u32, _u32, _u32, _u32, _P(DetectorGeometry), _vp, _sz, _sz]),
     "paris_hip_backproject": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _vp, _u32, _u32, _u32, _u32,
                                         _P(DetectorGeometry), _P(VolumeGeometry), C.c_int,
                                         _P(RegionOfInterest), _f, _f, _f, _f]),

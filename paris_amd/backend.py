@@ -470,6 +470,15 @@ def weight_filter_rows(backend, p, det_geo, row_first, row_count, half_ptr=None,
                                                         C.byref(det_geo), half_ptr, half_pitch), "paris_hip_stage_weight_filter_rows")
 
 
+def weight_filter_batch(backend, ptr, pitch, frame_stride, n_frames, dim_x, dim_y, det_geo, row_first, row_count, half_ptr=None,
+                        half_pitch=0, half_frame_stride=0):
+    """paris::weight + paris::filter of a row band for a group of n_frames projections frame_stride bytes apart, in ONE launch
+    (paris_hip_stage_weight_filter_batch); bit-identical to the per-frame calls"""
+    check(backend._L.paris_hip_stage_weight_filter_batch(backend._ctx, ptr, pitch, frame_stride, n_frames, dim_x, dim_y, row_first,
+                                                         row_count, C.byref(det_geo), half_ptr, half_pitch, half_frame_stride),
+          "paris_hip_stage_weight_filter_batch")
+
+
 def backproject(backend, p, v, v_offset, det_geo, vol_geo, enable_angles, enable_roi, roi):
     """paris::backproject (src/backprojection.cpp:37-69)"""
     r = roi if roi is not None else RegionOfInterest()

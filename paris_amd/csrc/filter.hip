@@ -629,6 +629,49 @@ extern "C" int paris_hip_weight_filter_rows(paris_hip_ctx* ctx, float* d_p, size
     return paris_hip_finish(ctx);
 }
 
+// Extension: paris_hip_weight_filter_rows for n_frames projections in ONE launch (grid.y = frame): frame f lives frame_stride bytes
+// behind frame f - 1 (d_half likewise, half_frame_stride bytes apart). What a driver that holds a group of uploaded frames wants
+// before its fused backprojection: for small detectors a launch per frame is mostly launch latency (512^2: 256 workgroups of one
+// wave, 6.9 us each; sixteen frames in one launch cost little more than one). Bit-identical to the per-frame calls (the same
+// workgroup per row pair). filter_size < 1024 or a foreign K: the frames are run one by one through the separate stages' entry.
+extern "C" int paris_hip_weight_filter_batch(paris_hip_ctx* ctx, float* d_p, size_t pitch, size_t frame_stride, uint32_t n_frames, uint32_t dim_x,
+                                             uint32_t dim_y, uint32_t row_first, uint32_t row_count, float h_min, float v_min, float d_sd,
+                                             float l_px_row, float l_px_col, const float* d_k, uint32_t filter_size, uint16_t* d_half,
+                                             size_t half_pitch, size_t half_frame_stride)
+{
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(int rc = paris_hip_flush_pending_weight(ctx))
+        return rc;
+    if(d_p == nullptr || d_k == nullptr || !is_pow2(filter_size) || filter_size < MIN_N || filter_size > MAX_N || dim_x > filter_size
+       || pitch < static_cast<size_t>(dim_x) * sizeof(float) || pitch % sizeof(float) != 0 || row_first > dim_y || row_count > dim_y - row_first
+       || (d_half != nullptr && (half_pitch < static_cast<size_t>(dim_x) * sizeof(uint16_t) || half_pitch % sizeof(uint16_t) != 0))
+       || n_frames > 65535u)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(n_frames > 1u && (frame_stride % sizeof(float) != 0 || frame_stride < pitch * static_cast<size_t>(dim_y)
+                         || (d_half != nullptr && (half_frame_stride % sizeof(uint16_t) != 0 || half_frame_stride < half_pitch * static_cast<size_t>(dim_y)))))
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT; // frames must not overlap
+    if(dim_x == 0 || row_count == 0 || n_frames == 0)
+        return paris_hip_finish(ctx);
+    const paris_hip_filter_info* info = fused_filter_of(ctx, d_k, filter_size);
+    if(info == nullptr)
+        return PARIS_HIP_ERROR_UNSUPPORTED;
+    paris_hip_fft_plan* plan = nullptr;
+    if(int rc = paris_hip_get_plan(ctx, filter_size, &plan))
+        return rc;
+    float* rows = reinterpret_cast<float*>(reinterpret_cast<char*>(d_p) + static_cast<size_t>(row_first) * pitch);
+    uint16_t* half_rows = d_half ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d_half) + static_cast<size_t>(row_first) * half_pitch) : nullptr;
+    if(int rc = paris_hip_fused_filter_launch(ctx, rows, static_cast<uint32_t>(pitch / sizeof(float)), dim_x, row_count, row_first, true, h_min, v_min,
+                                              d_sd, l_px_row, l_px_col, info->d_kp, plan, filter_size, half_rows,
+                                              static_cast<uint32_t>(half_pitch / sizeof(uint16_t)), n_frames, frame_stride / sizeof(float),
+                                              half_frame_stride / sizeof(uint16_t)))
+        return rc;
+    for(uint32_t f = 0; f < n_frames && !ctx->upload_targets.empty(); ++f)
+        if(int rc = paris_hip_note_projection_use(ctx, reinterpret_cast<char*>(rows) + f * frame_stride, pitch * row_count))
+            return rc;
+    return paris_hip_finish(ctx);
+}
+
 extern "C" int paris_hip_set_filter_variant(paris_hip_ctx* ctx, int variant)
 {
     if(ctx == nullptr || variant < 0 || variant > 2)

@@ -217,6 +217,9 @@ namespace
         const float2* tab_mid[3]; // middle pass with block B = 16^(k + 2): [(q - 1) * (B / 16) + o] = W_B^(o q), q = 1 .. 15
         _Float16* half_out;      // F16OUT: destination of the filtered rows (first row of the band)
         uint32_t half_pitch;     // halves per row
+        // several frames per launch (grid.y = frame): frame f's band starts frame_stride floats (half_frame_stride halves) behind
+        // frame f - 1's; the detector row indices, hence the weights, are the same for every frame
+        size_t frame_stride, half_frame_stride;
     };
 
     // HALF: dim_x <= N/2 (always true for the reference's filter length 2 * 2^ceil(log2 n_row)); WEIGHT: apply the cosine
@@ -240,8 +243,10 @@ namespace
         const uint32_t row_a = 2u * blockIdx.x;
         const uint32_t row_b = row_a + 1u;
         const bool has_b = row_b < a.n_rows;
-        float* pa = a.p + static_cast<size_t>(row_a) * a.pitch_f;
-        float* pb = a.p + static_cast<size_t>(row_b) * a.pitch_f;
+        float* frame = a.p + static_cast<size_t>(blockIdx.y) * a.frame_stride;
+        _Float16* half_frame = F16OUT ? a.half_out + static_cast<size_t>(blockIdx.y) * a.half_frame_stride : nullptr;
+        float* pa = frame + static_cast<size_t>(row_a) * a.pitch_f;
+        float* pb = frame + static_cast<size_t>(row_b) * a.pitch_f;
         float vv_a = 0.f, vv_b = 0.f;
         if(WEIGHT)
         {
@@ -454,9 +459,9 @@ namespace
                 {
                     if(F16OUT)
                     {
-                        a.half_out[static_cast<size_t>(row_a) * a.half_pitch + idx] = static_cast<_Float16>(v[j].x * inv_n);
+                        half_frame[static_cast<size_t>(row_a) * a.half_pitch + idx] = static_cast<_Float16>(v[j].x * inv_n);
                         if(has_b)
-                            a.half_out[static_cast<size_t>(row_b) * a.half_pitch + idx] = static_cast<_Float16>(v[j].y * inv_n);
+                            half_frame[static_cast<size_t>(row_b) * a.half_pitch + idx] = static_cast<_Float16>(v[j].y * inv_n);
                     }
                     else
                     {
@@ -507,30 +512,30 @@ namespace
     }
 
     template <int LOG2N, bool HALF, bool WEIGHT, bool F16OUT>
-    int launch(paris_hip_ctx* ctx, const FusedFilterArgs& a)
+    int launch(paris_hip_ctx* ctx, const FusedFilterArgs& a, uint32_t n_frames)
     {
         constexpr uint32_t N = 1u << LOG2N;
         constexpr uint32_t lds_bytes = (N + N / 16u + 15u * 16u) * sizeof(float2); // data + the block-256 twiddles
         if(lds_bytes > 64u * 1024u)
             PARIS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_rows_kernel<LOG2N, HALF, WEIGHT, F16OUT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        hipLaunchKernelGGL((filter_rows_kernel<LOG2N, HALF, WEIGHT, F16OUT>), dim3((a.n_rows + 1u) / 2u), dim3(N / 16u), lds_bytes,
+        hipLaunchKernelGGL((filter_rows_kernel<LOG2N, HALF, WEIGHT, F16OUT>), dim3((a.n_rows + 1u) / 2u, n_frames), dim3(N / 16u), lds_bytes,
                            ctx->stream, a);
         return PARIS_HIP_SUCCESS;
     }
 
     template <int LOG2N>
-    int launch_flags(paris_hip_ctx* ctx, const FusedFilterArgs& a, bool half_ok, bool weight, bool f16out)
+    int launch_flags(paris_hip_ctx* ctx, const FusedFilterArgs& a, bool half_ok, bool weight, bool f16out, uint32_t n)
     {
         if(f16out)
         {
             if(half_ok)
-                return weight ? launch<LOG2N, true, true, true>(ctx, a) : launch<LOG2N, true, false, true>(ctx, a);
-            return weight ? launch<LOG2N, false, true, true>(ctx, a) : launch<LOG2N, false, false, true>(ctx, a);
+                return weight ? launch<LOG2N, true, true, true>(ctx, a, n) : launch<LOG2N, true, false, true>(ctx, a, n);
+            return weight ? launch<LOG2N, false, true, true>(ctx, a, n) : launch<LOG2N, false, false, true>(ctx, a, n);
         }
         if(half_ok)
-            return weight ? launch<LOG2N, true, true, false>(ctx, a) : launch<LOG2N, true, false, false>(ctx, a);
-        return weight ? launch<LOG2N, false, true, false>(ctx, a) : launch<LOG2N, false, false, false>(ctx, a);
+            return weight ? launch<LOG2N, true, true, false>(ctx, a, n) : launch<LOG2N, true, false, false>(ctx, a, n);
+        return weight ? launch<LOG2N, false, true, false>(ctx, a, n) : launch<LOG2N, false, false, false>(ctx, a, n);
     }
 
     uint32_t ilog2(uint32_t v)
@@ -602,9 +607,14 @@ int paris_hip_fused_filter_permute_k(paris_hip_ctx* ctx, const float* d_k, uint3
 
 int paris_hip_fused_filter_launch(paris_hip_ctx* ctx, float* d_rows, uint32_t pitch_f, uint32_t dim_x, uint32_t n_rows, uint32_t row_first,
                                   bool weight, float h_min, float v_min, float d_sd, float l_px_row, float l_px_col, const float* d_kp,
-                                  const paris_hip_fft_plan* plan, uint32_t filter_size, uint16_t* d_half, uint32_t half_pitch)
+                                  const paris_hip_fft_plan* plan, uint32_t filter_size, uint16_t* d_half, uint32_t half_pitch, uint32_t n_frames,
+                                  size_t frame_stride_f, size_t half_frame_stride)
 {
+    if(n_frames == 0u || n_frames > 65535u)
+        return n_frames == 0u ? PARIS_HIP_SUCCESS : PARIS_HIP_ERROR_INVALID_ARGUMENT;
     FusedFilterArgs a{};
+    a.frame_stride = frame_stride_f;
+    a.half_frame_stride = half_frame_stride;
     a.p = d_rows;
     a.pitch_f = pitch_f;
     a.dim_x = dim_x;
@@ -633,11 +643,11 @@ int paris_hip_fused_filter_launch(paris_hip_ctx* ctx, float* d_rows, uint32_t pi
     const bool f16out = d_half != nullptr;
     switch(ilog2(filter_size))
     {
-        case 10: return launch_flags<10>(ctx, a, half_ok, weight, f16out);
-        case 11: return launch_flags<11>(ctx, a, half_ok, weight, f16out);
-        case 12: return launch_flags<12>(ctx, a, half_ok, weight, f16out);
-        case 13: return launch_flags<13>(ctx, a, half_ok, weight, f16out);
-        case 14: return launch_flags<14>(ctx, a, half_ok, weight, f16out);
+        case 10: return launch_flags<10>(ctx, a, half_ok, weight, f16out, n_frames);
+        case 11: return launch_flags<11>(ctx, a, half_ok, weight, f16out, n_frames);
+        case 12: return launch_flags<12>(ctx, a, half_ok, weight, f16out, n_frames);
+        case 13: return launch_flags<13>(ctx, a, half_ok, weight, f16out, n_frames);
+        case 14: return launch_flags<14>(ctx, a, half_ok, weight, f16out, n_frames);
         default: return PARIS_HIP_ERROR_UNSUPPORTED;
     }
 }

@@ -212,7 +212,8 @@ int paris_hip_fused_filter_tables(paris_hip_ctx* ctx, uint32_t n, paris_hip_fft_
 int paris_hip_fused_filter_permute_k(paris_hip_ctx* ctx, const float* d_k, uint32_t n, float** d_kp);
 int paris_hip_fused_filter_launch(paris_hip_ctx* ctx, float* d_rows, uint32_t pitch_f, uint32_t dim_x, uint32_t n_rows, uint32_t row_first,
                                   bool weight, float h_min, float v_min, float d_sd, float l_px_row, float l_px_col, const float* d_kp,
-                                  const paris_hip_fft_plan* plan, uint32_t filter_size, uint16_t* d_half, uint32_t half_pitch);
+                                  const paris_hip_fft_plan* plan, uint32_t filter_size, uint16_t* d_half, uint32_t half_pitch,
+                                  uint32_t n_frames = 1u, size_t frame_stride_f = 0u, size_t half_frame_stride = 0u);
 
 // backproject.hip: runs the projections pending in the deferral ring (no-op when there are none). Called by every entry
 // point that observes or changes a volume, completes work, or changes how backprojection runs.

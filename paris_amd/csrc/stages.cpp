@@ -163,6 +163,37 @@ extern "C" int paris_hip_stage_weight_filter_rows(paris_hip_ctx* ctx, float* d_p
                                             half_pitch, dim_x, row_count);
 }
 
+// Extension: paris_hip_stage_weight_filter_rows for a group of n_frames projections frame_stride bytes apart, in one launch
+// (paris_hip_weight_filter_batch); narrow detectors (filter length < 1024) run frame by frame: same result.
+extern "C" int paris_hip_stage_weight_filter_batch(paris_hip_ctx* ctx, float* d_p, size_t pitch, size_t frame_stride, uint32_t n_frames,
+                                                   uint32_t dim_x, uint32_t dim_y, uint32_t row_first, uint32_t row_count,
+                                                   const paris_detector_geometry* det_geo, uint16_t* d_half, size_t half_pitch,
+                                                   size_t half_frame_stride)
+{
+    if(ctx == nullptr || det_geo == nullptr || d_p == nullptr || row_first > dim_y || row_count > dim_y - row_first)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    const uint32_t filter_size = paris_hip_filter_size(det_geo->n_row);
+    if(filter_size >= 1024u && ctx->filter_variant == 0)
+    {
+        if(int rc = paris_hip_stage_filter_rows(ctx, d_p, pitch, dim_x, dim_y, row_first, 0u, det_geo)) // builds / finds the cached K
+            return rc;
+        const float n_row_f = static_cast<float>(det_geo->n_row);
+        const float n_col_f = static_cast<float>(det_geo->n_col);
+        const float h_min = (det_geo->delta_s * det_geo->l_px_row) - ((n_row_f * det_geo->l_px_row) / 2); // src/weighting.cpp:37-42
+        const float v_min = (det_geo->delta_t * det_geo->l_px_col) - ((n_col_f * det_geo->l_px_col) / 2);
+        const float d_sd = std::abs(det_geo->d_so) + std::abs(det_geo->d_od);
+        return paris_hip_weight_filter_batch(ctx, d_p, pitch, frame_stride, n_frames, dim_x, dim_y, row_first, row_count, h_min, v_min, d_sd,
+                                             det_geo->l_px_row, det_geo->l_px_col, ctx->stage_k, filter_size, d_half, half_pitch, half_frame_stride);
+    }
+    for(uint32_t f = 0; f < n_frames; ++f)
+        if(int rc = paris_hip_stage_weight_filter_rows(ctx, reinterpret_cast<float*>(reinterpret_cast<char*>(d_p) + f * frame_stride), pitch, dim_x, dim_y,
+                                                       row_first, row_count, det_geo,
+                                                       d_half ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d_half) + f * half_frame_stride) : nullptr,
+                                                       half_pitch))
+            return rc;
+    return PARIS_HIP_SUCCESS;
+}
+
 extern "C" int paris_hip_stage_filter(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_t dim_x, uint32_t dim_y,
                                       const paris_detector_geometry* det_geo)
 {

@@ -357,10 +357,18 @@ namespace paris
                 std::uint32_t group = 0, filled = 0; // frames of the current group already enqueued
                 auto sines = std::vector<float>(batch), cosines = std::vector<float>(batch);
                 const float delta_s = t.det_geo.delta_s * t.det_geo.l_px_row, delta_t = t.det_geo.delta_t * t.det_geo.l_px_col; // src/backprojection.cpp:49-50
+                // frames of up to 1024 x 1024 are weighted and filtered group by group (one launch for up to `batch` frames when the
+                // group is flushed) instead of frame by frame behind each upload: their launches are mostly latency
+                const bool filter_by_group = batch > 1u && static_cast<std::uint64_t>(n_row) * n_col <= (1ull << 20);
                 const auto flush = [&] { // one fused launch for the frames of the current group, then on to the other group
                     if(filled == 0)
                         return;
                     const auto t1 = clock::now();
+                    if(filter_by_group && band_count != 0)
+                        rt(paris_hip_stage_weight_filter_batch(ctx, d_buf[group * batch], d_pitch, d_stride, filled, n_row, n_col, band_first, band_count,
+                                                               &t.det_geo,
+                                                               po.f16 ? reinterpret_cast<std::uint16_t*>(reinterpret_cast<char*>(d_half) + h16_stride * group * batch) : nullptr,
+                                                               h16_pitch, h16_stride), "weight() + filter()");
                     if(po.f16)
                         rt(paris_hip_backproject_batch_f16(ctx, reinterpret_cast<const std::uint16_t*>(reinterpret_cast<const char*>(d_half) + h16_stride * group * batch),
                                                            h16_pitch, h16_stride, filled, n_row, n_col, d_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z,
@@ -401,9 +409,11 @@ namespace paris
                         rt(paris_hip_upload_projection(ctx, d_band, d_pitch, h_buf[slot] + band_off, row_bytes, n_row, band_count), "load()");
                         // :102-103 in one launch: the weight rides along in the row filter's load; with --f16 (BASELINE config 5) the
                         // filtered band is stored as IEEE half straight into the slot's half frame
+                        // (small frames: the whole group by one launch when it is flushed -- a launch per 512^2 frame is mostly latency)
                         auto* half_frame = po.f16 ? reinterpret_cast<std::uint16_t*>(reinterpret_cast<char*>(d_half) + h16_stride * static_cast<std::size_t>(slot)) : nullptr;
-                        rt(paris_hip_stage_weight_filter_rows(ctx, d_buf[slot], d_pitch, n_row, n_col, band_first, band_count, &t.det_geo, half_frame,
-                                                              h16_pitch), "weight() + filter()");
+                        if(!filter_by_group)
+                            rt(paris_hip_stage_weight_filter_rows(ctx, d_buf[slot], d_pitch, n_row, n_col, band_first, band_count, &t.det_geo, half_frame,
+                                                                  h16_pitch), "weight() + filter()");
                     }
                     rt(paris_hip_stage_angle(&t.det_geo, p.idx, t.enable_angles, p.phi, &sines[filled], &cosines[filled]), "angle"); // src/backprojection.cpp:52-63
                     rep.enqueue_s += since(t0);

@@ -1382,6 +1382,65 @@ def test_deferred_groups_on_the_second_stream(oracle, kat_golden, overlap):
         assert_bit_equal(volume_to_host(abe, d_w), want5)
 
 
+@pytest.mark.parametrize("n,rows,band", [(512, 37, (6, 20)), (1024, 16, (0, 16)), (700, 9, (2, 7))])
+def test_weight_filter_batch_equals_per_frame_calls(be, oracle, n, rows, band):
+    """paris_hip_stage_weight_filter_batch: a group of frames weighted and filtered by ONE launch (grid.y = frame) is bit-identical
+    to the per-frame paris_hip_stage_weight_filter_rows calls -- fp32 in place and the half-precision store, a row band with an odd
+    first / last pair, frames a non-trivial stride apart; rows outside the band keep their values; against the oracle to the
+    filter tolerance."""
+    g = (n, rows, 0.2, 0.25, 0.5, -0.25, 400, 300, 1.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    n_frames = 5
+    frames = [oracle.lcg_projection(n, rows, 11 + i) for i in range(n_frames)]
+    first, count = band
+    pad = 3  # rows of slack between frames
+    stack_rows = (rows + pad) * n_frames
+    host = np.full((stack_rows, n), np.float32(-7.0))
+    for i, f in enumerate(frames):
+        host[i * (rows + pad):i * (rows + pad) + rows] = f
+    a = be.make_projection_device(n, stack_rows)
+    b = be.make_projection_device(n, stack_rows)
+    for d in (a, b):
+        be.copy_h2d(B.Projection(host.copy(), n, stack_rows), d)
+    stride = a.pitch * (rows + pad)
+    half_pitch = n * 2
+    half_stride = half_pitch * (rows + pad)
+    import torch
+    dev = torch.device("cuda", 0)
+    ha = torch.zeros((stack_rows, n), dtype=torch.float16, device=dev)
+    hb = torch.zeros((stack_rows, n), dtype=torch.float16, device=dev)
+    torch.cuda.synchronize()
+    # one launch for the group
+    B.weight_filter_batch(be, a.ptr, a.pitch, stride, n_frames, n, rows, det, first, count)
+    B.weight_filter_batch(be, b.ptr, b.pitch, stride, n_frames, n, rows, det, first, count, ha.data_ptr(), half_pitch, half_stride)
+    got_batch = to_host(be, a)
+    raw_after_half = to_host(be, b)
+    # frame by frame
+    c = be.make_projection_device(n, stack_rows)
+    be.copy_h2d(B.Projection(host.copy(), n, stack_rows), c)
+    for i in range(n_frames):
+        p = be.wrap_projection(c.ptr + i * stride, c.pitch, n, rows)
+        B.weight_filter_rows(be, p, det, first, count)
+        q = be.wrap_projection(b.ptr + i * stride, b.pitch, n, rows)
+        B.weight_filter_rows(be, q, det, first, count, hb.data_ptr() + i * half_stride, half_pitch)
+    be.synchronize()
+    got_single = to_host(be, c)
+    assert np.array_equal(got_batch.view(np.uint32), got_single.view(np.uint32))
+    assert np.array_equal(raw_after_half, host)  # the half store leaves the fp32 rows alone
+    assert torch.equal(ha.view(torch.int16), hb.view(torch.int16))
+    fs = oracle.filter_size(n)
+    k = oracle.make_filter(fs, det.l_px_row)
+    for i, f in enumerate(frames):
+        r0 = i * (rows + pad)
+        want = oracle.apply_filter(oracle.weight(f.copy(), odet), k, fs)
+        blk = got_batch[r0:r0 + rows]
+        assert np.max(np.abs(blk[first:first + count] - want[first:first + count])) <= FILTER_TOL * np.abs(want).max()
+        assert np.array_equal(blk[:first], f[:first]) and np.array_equal(blk[first + count:], f[first + count:])
+        assert np.all(got_batch[r0 + rows:r0 + rows + pad] == np.float32(-7.0))
+    for d in (a, b, c):
+        be.free(d)
+
+
 def device_view(torch, v, dev):
     """a torch tensor over a library-allocated volume (z, y, x): the same memory, no copy"""
     class _Mem:
