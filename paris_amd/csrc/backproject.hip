@@ -727,6 +727,17 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         int vx = lane_width(d_v, v_dim_x); // unless the tuning knob asks for less
         if(ctx->bp_vx && ctx->bp_vx < vx)
             vx = ctx->bp_vx;
+        // A small volume cut into 64 x 16 x tz tiles is ONE generation of workgroups or less (256^3: 1024 = 4 per CU), and the
+        // launch is then a latency chain -- every workgroup computes its box and columns, stages, and only then streams. Tiles of
+        // 64 x 8 columns (two voxels per lane, 8-byte accesses) double the workgroups, so that one's prologue runs under
+        // another's stream: 28.5 -> 26.4 us at 256^3 (profiles/r03_ab_c1_tile.txt; the volume lives in the Infinity Cache there,
+        // the narrower accesses cost nothing)
+        if(ctx->bp_vx == 0 && vx == 4 && ctx->bp_variant != 3 && ctx->bp_variant != 5)
+        {
+            const uint64_t tiles = static_cast<uint64_t>((v_dim_x + 63u) / 64u) * ((v_dim_y + 15u) / 16u) * ((v_dim_z + g.tz - 1u) / g.tz);
+            if(tiles < 2048u)
+                vx = 2;
+        }
         // slices in flight per lane: 2 (interleaved A/B on 2048^3: tools/ab_bp.py, profiles/); with the 8-slice tiles of
         // 1024^2 planes one slice plus the prefetch of the next is as fast and leaves more registers
         const int unroll = ctx->bp_unroll ? ctx->bp_unroll : (g.tz == 8u && ctx->bp_tz == 0u ? 1 : 2);
