@@ -211,7 +211,8 @@ int paris_hip_set_backproject_skip_invalid(paris_hip_ctx* ctx, int enable);
  * that overlaps [d_ptr, d_ptr + bytes) takes every addition from then on (until a paris_hip_memset_volume covers it whole again).
  * paris_hip_volume_mark_clean is the opposite promise, for ANY device memory, the caller's own included: the range holds no -0
  * right now (freshly zero-filled; written by nothing but backprojections since) and the caller will mark it dirty before writing
- * anything else into it. Writing zeros (hipMemset, tensor.zero_()) needs neither call. */
+ * anything else into it -- and before releasing memory the library did not allocate: the entry is keyed by address and would vouch
+ * for whatever is mapped there next. Writing zeros (hipMemset, tensor.zero_()) needs neither call. */
 int paris_hip_volume_mark_dirty(paris_hip_ctx* ctx, const void* d_ptr, size_t bytes);
 int paris_hip_volume_mark_clean(paris_hip_ctx* ctx, const void* d_ptr, size_t bytes);
 

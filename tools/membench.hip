@@ -88,6 +88,18 @@ __device__ __forceinline__ void tile_of(uint32_t b, uint32_t order, uint32_t ntx
         bx = r % ntx; r /= ntx; by = xcd * band + r % band; bz = r / band;
         return;
     }
+    if(order >= 140u) // the dealt orders of round 3: order = 100 * kernel order (14 .. 17) + z tiles per chunk; y tiles dealt to the XCDs in groups
+    {
+        const uint32_t grp = 1u << (order / 100u - 14u), zchunk = order % 100u ? order % 100u : ntz;
+        const uint32_t band = nty / 8u, xcd = b % 8u;
+        uint32_t r = b / 8u;
+        bx = r % ntx; r /= ntx;
+        const uint32_t zl = r % zchunk; r /= zchunk;
+        const uint32_t yb = r % band;
+        bz = (r / band) * zchunk + zl;
+        by = (yb / grp) * (8u * grp) + xcd * grp + yb % grp;
+        return;
+    }
     if(order == 5u) { const uint32_t per = (ntx * nty * ntz) / 8u; b = (b % 8u) * per + b / 8u; }
     bx = b % ntx; b /= ntx; by = b % nty; bz = b / nty;
 }
@@ -253,6 +265,14 @@ int main(int argc, char** argv)
             add(nm, [=] { tile<16, 2, NTSC1><<<g16, 256>>>(a, dx, dy, dz, tz, order); });
             snprintf(nm, sizeof nm, "tile 256x4x%u order %u if2 ntsc1", tz, order);
             add(nm, [=] { tile<64, 2, NTSC1><<<g64, 256>>>(a, dx, dy, dz, tz, order); });
+        }
+    for(uint32_t order : {1400u, 1404u, 1500u, 1504u, 1502u, 1501u, 1508u, 1604u})
+        for(uint32_t tz : {16u, 8u})
+        {
+            const unsigned g16 = (dx / 64) * (dy / 16) * (dz / tz);
+            char nm[128];
+            snprintf(nm, sizeof nm, "dealt tile 64x16x%u order %u (groups of %u y tiles, %u z tiles per chunk) if2 ntsc1", tz, order / 100u, 1u << (order / 100u - 14u), order % 100u);
+            add(nm, [=] { tile<16, 2, NTSC1><<<g16, 256>>>(a, dx, dy, dz, tz, order); });
         }
     {
         const unsigned g = (dx / 64) * (dy / 16) * (dz / 16);
