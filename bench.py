@@ -83,6 +83,53 @@ def measured_traffic(w, world):
     return best if best else (None, None, None)
 
 
+def live_traffic(argv_tail, launches=16):
+    """HBM bytes per backprojection launch measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE,
+    then WRITE_SIZE: separate passes, nothing else traced, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), each adding
+    `launches` projections spread over the whole circle. Must be called before this process touches the GPU (the children are
+    ordinary child processes; the profiler starts `python3 bench.py ...` directly). Corrections as in tools/pmc_traffic.py: both
+    counters are in KiB, FETCH_SIZE counts half the bytes of wide streaming reads on gfx950. None when the profiler is absent or a
+    pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return None
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    child = ["python3", os.path.join(ROOT, "bench.py")] + argv_tail + [
+        "--live-traffic", "0", "--steps", "1", "--warmup", "0", "--batch", str(launches), "--spread", "1", "--cpu-budget", "0",
+        "--cpu-c1", "0", "--noskip-step", "0", "--fused-steps", "0"]
+    out = {}
+    work = tempfile.mkdtemp(prefix="paris_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            r = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+            files = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            with open(files[0]) as f:
+                vals = [float(row["Counter_Value"]) for row in csv.DictReader(f)
+                        if "bp_tile" in row["Kernel_Name"] and row["Counter_Name"] == counter]
+            if len(vals) != launches:
+                return None
+            out[counter] = vals
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    per_launch = [a * 2048.0 + b * 1024.0 for a, b in zip(out["FETCH_SIZE"], out["WRITE_SIZE"])]
+    return {"bytes_per_launch": sum(per_launch) / len(per_launch), "min": min(per_launch), "max": max(per_launch),
+            "launches": launches}
+
+
 def kernel_source_sha16():
     """fingerprint of the backprojection kernel's sources (as tools/pmc_traffic.py records it)"""
     import hashlib
@@ -331,6 +378,9 @@ def main():
     ap.add_argument("--overlap", type=int, default=0, help="deferred_boundary leg: 1 = fused launches of deferred calls on the ctx's "
                     "second stream beside the next group's copies and filters (paris_hip_set_backproject_overlap); 0 (default, the "
                     "library's default) = on the ctx stream")
+    ap.add_argument("--live-traffic", type=int, default=1, help="1 (default; N = 1, config 3 only): roofline.traffic is measured in this "
+                    "run -- before the GPU is touched, two child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` add 16 "
+                    "projections spread over the circle each (about 20 s per pass); 0: the newest matching record under profiles/")
     ap.add_argument("--spread", type=int, default=0, help="1: with a partial job (--batch), the timed projections are spread evenly "
                     "over the circle instead of taken from its start (counter runs: a few launches that sample every angle)")
     ap.add_argument("--slices", type=int, default=0, help="rehearsal only: cap the volume depth (0 = the workload's)")
@@ -345,6 +395,16 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    # roofline.traffic, measured live: child processes under the profiler, before this process initialises the GPU
+    live = None
+    under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if (args.live_traffic and args.gpus == 1 and args.workload == "c3" and args.slices == 0 and "RANK" not in os.environ
+            and not under_profiler):
+        tail = []
+        for name in ("vx", "unroll", "tz", "lds_bytes", "variant", "order", "row_band", "stage_fusion"):
+            tail += ["--" + name.replace("_", "-"), str(getattr(args, name))]
+        live = live_traffic(tail)
 
     import torch
 
@@ -671,6 +731,13 @@ def main():
 
     if rank == 0:
         traffic, traffic_src, traffic_sha = measured_traffic(w, world)
+        traffic_live = False
+        if live is not None:
+            traffic, traffic_sha, traffic_live = live["bytes_per_launch"], kernel_source_sha16(), True
+            traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around child runs of "
+                           "bench.py adding %d projections spread over the circle; FETCH_SIZE x 2048 (KiB, gfx950 half-count of wide "
+                           "streaming reads) + WRITE_SIZE x 1024; per-launch min %.4g max %.4g bytes"
+                           % (live["launches"], live["min"], live["max"]))
         avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         algo_bytes = 8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col  # per launch: RMW of the slab + one projection pass
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -713,7 +780,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_this_run": traffic_live,
                 # the counters come from a committed rocprofv3 --pmc run (they cannot be read inside this process): stale when the
                 # kernel's sources have changed since
                 "traffic_is_of_this_kernel": (traffic_sha == kernel_source_sha16()) if traffic is not None else None,

@@ -19,7 +19,7 @@ LIB = os.path.join(ROOT, "paris_amd", "lib", "libparis_hip.so")
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=2)
-ap.add_argument("--common", default="--steps 10 --warmup 2 --cpu-budget 0 --cpu-c1 0")
+ap.add_argument("--common", default="--steps 10 --warmup 2 --cpu-budget 0 --cpu-c1 0 --live-traffic 0")
 ap.add_argument("configs", nargs="+")
 args = ap.parse_args()
 

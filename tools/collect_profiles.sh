@@ -12,13 +12,13 @@ export TMPDIR=/tmp
 run() { echo "== $*" >&2; "$@"; }
 # 1. counters first: bench.py's roofline.traffic and fused_extension.roofline read the newest records under profiles/
 #    (one --pmc pass each, nothing else traced); kernel times for the derived figures come from an unprofiled run
-run python bench.py --steps 8 --warmup 2 --cpu-budget 0 --cpu-c1 0 > $out/quick.json
-A="--steps 1 --warmup 1 --batch 16 --spread 1 --cpu-budget 0 --cpu-c1 0 --noskip-step 0"  # 16 timed launches that sample the whole circle
+run python bench.py --steps 8 --warmup 2 --cpu-budget 0 --cpu-c1 0 --live-traffic 0 > $out/quick.json
+A="--steps 1 --warmup 1 --batch 16 --spread 1 --cpu-budget 0 --cpu-c1 0 --noskip-step 0 --live-traffic 0"  # 16 timed launches that sample the whole circle
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/prof_fetch -- python3 bench.py $A > /dev/null
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/prof_write -- python3 bench.py $A > /dev/null
 python tools/pmc_traffic.py $out/prof_fetch $out/prof_write "2048^3 volume, 1440 projections @ 2048x2048 fp32" $out/${tag}_pmc_traffic_c3.json
 echo "traffic done" >&2
-S="--steps 1 --warmup 1 --batch 8 --spread 1 --cpu-budget 0 --cpu-c1 0 --noskip-step 0 --fused-steps 1"
+S="--steps 1 --warmup 1 --batch 8 --spread 1 --cpu-budget 0 --cpu-c1 0 --noskip-step 0 --live-traffic 0 --fused-steps 1"
 run rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $out/pmc_sq_a -- python3 bench.py $S > /dev/null
 run rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_sq_b -- python3 bench.py $S > /dev/null
 python tools/pmc_sq.py $out/pmc_sq_a $out/pmc_sq_b $out/quick.json $out/${tag}_pmc_sq_counters_c3.json "$S"
@@ -35,7 +35,7 @@ run python bench.py --steps 20 --warmup 5 --workload c1 --graph 1 --cpu-budget 0
 run python bench.py --steps 20 --warmup 5 --workload c5 --cpu-budget 0 --cpu-c1 0 > $out/${tag}_bench_c5_1gpu.json
 echo "benches done" >&2
 # 3. the same default command under the profiler (kernel trace only)
-run rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 5 --cpu-budget 0 --cpu-c1 0 > $out/${tag}_bench_under_rocprof_c3.json
+run rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 5 --cpu-budget 0 --cpu-c1 0 --live-traffic 0 > $out/${tag}_bench_under_rocprof_c3.json
 cp $(ls $out/stats/*/*_kernel_stats.csv | head -1) $out/${tag}_kernel_stats_bench_c3_whole_job.csv
 echo "kernel stats done" >&2
 rm -rf $out/stats $out/prof_fetch $out/prof_write $out/pmc_sq_a $out/pmc_sq_b $out/pmc_w1 $out/quick.json
