@@ -83,13 +83,13 @@ def measured_traffic(w, world):
     return best if best else (None, None, None)
 
 
-def live_traffic(argv_tail, launches=16):
-    """HBM bytes per backprojection launch measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE,
-    then WRITE_SIZE: separate passes, nothing else traced, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), each adding
-    `launches` projections spread over the whole circle. Must be called before this process touches the GPU (the children are
-    ordinary child processes; the profiler starts `python3 bench.py ...` directly). Corrections as in tools/pmc_traffic.py: both
-    counters are in KiB, FETCH_SIZE counts half the bytes of wide streaming reads on gfx950. None when the profiler is absent or a
-    pass fails."""
+def live_counters(argv_tail, launches=16, fused_batch=16):
+    """Counters measured NOW, by child runs of this script under `rocprofv3 --pmc`, one counter per pass and nothing else traced
+    (/opt/skills/guides/MI355X_MICROARCH.md): FETCH_SIZE and WRITE_SIZE around `launches` single-projection launches spread over the
+    whole circle (HBM bytes per launch: both counters are in KiB, FETCH_SIZE counts half the bytes of wide streaming reads on
+    gfx950), and SQ_INSTS_VALU around a few fused launches (wave-level vector instructions; x 64 lanes / voxel-updates of a launch
+    = instructions per voxel-update). Must be called before this process touches the GPU: the children are ordinary child
+    processes and the profiler starts `python3 bench.py ...` directly. A pass that fails leaves its figure out."""
     import csv
     import glob
     import shutil
@@ -97,37 +97,44 @@ def live_traffic(argv_tail, launches=16):
     import tempfile
     prof = shutil.which("rocprofv3")
     if prof is None:
-        return None
+        return {}
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    child = ["python3", os.path.join(ROOT, "bench.py")] + argv_tail + [
-        "--live-traffic", "0", "--steps", "1", "--warmup", "0", "--batch", str(launches), "--spread", "1", "--cpu-budget", "0",
-        "--cpu-c1", "0", "--noskip-step", "0", "--fused-steps", "0"]
-    out = {}
+    base = ["python3", os.path.join(ROOT, "bench.py")] + argv_tail + ["--live-traffic", "0", "--steps", "1", "--warmup", "0", "--spread", "1",
+                                                                      "--cpu-budget", "0", "--cpu-c1", "0", "--noskip-step", "0"]
+    single = base + ["--batch", str(launches), "--fused-steps", "0"]
+    fused = base + ["--batch", "1", "--fused-steps", "2", "--fused-batch", str(fused_batch)]
     work = tempfile.mkdtemp(prefix="paris_pmc_", dir="/tmp")
+
+    def one_pass(counter, child, kernel):
+        d = os.path.join(work, counter)
+        r = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        files = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)
+        if r.returncode != 0 or not files:
+            return None
+        with open(files[0]) as f:
+            return [float(row["Counter_Value"]) for row in csv.DictReader(f)
+                    if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter]
+
+    out = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(work, counter)
-            r = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-            files = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)
-            if r.returncode != 0 or not files:
-                return None
-            with open(files[0]) as f:
-                vals = [float(row["Counter_Value"]) for row in csv.DictReader(f)
-                        if "bp_tile" in row["Kernel_Name"] and row["Counter_Name"] == counter]
-            if len(vals) != launches:
-                return None
-            out[counter] = vals
+        fetch = one_pass("FETCH_SIZE", single, "bp_tile")
+        write = one_pass("WRITE_SIZE", single, "bp_tile") if fetch else None
+        if fetch and write and len(fetch) == launches == len(write):
+            per_launch = [a * 2048.0 + b * 1024.0 for a, b in zip(fetch, write)]
+            out["traffic"] = {"bytes_per_launch": sum(per_launch) / len(per_launch), "min": min(per_launch), "max": max(per_launch),
+                              "launches": launches}
+        valu = one_pass("SQ_INSTS_VALU", fused, "bp_fused")
+        if valu:
+            out["fused_valu"] = {"wave_instructions_per_launch": sum(valu) / len(valu), "launches": len(valu)}
     except (OSError, subprocess.SubprocessError, KeyError, ValueError):
-        return None
+        pass
     finally:
         shutil.rmtree(work, ignore_errors=True)
-    per_launch = [a * 2048.0 + b * 1024.0 for a, b in zip(out["FETCH_SIZE"], out["WRITE_SIZE"])]
-    return {"bytes_per_launch": sum(per_launch) / len(per_launch), "min": min(per_launch), "max": max(per_launch),
-            "launches": launches}
+    return out
 
 
 def kernel_source_sha16():
@@ -286,7 +293,7 @@ def fused_sq_profile():
     return None, None
 
 
-def fused_report(fused, fb, f16, voxels_rank, voxels_all, n_row, n_col, per_launch):
+def fused_report(fused, fb, f16, voxels_rank, voxels_all, n_row, n_col, per_launch, live_valu=None):
     rate = per_launch / (fused["kernel_ms"] * 1e-3) if fused["kernel_ms"] > 0 else 0.0  # voxel-updates/s of the kernel
     hbm_gbps = ((8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col * fb) / (fused["kernel_ms"] * 1e-3) / 1e9
                 if fused["kernel_ms"] > 0 else 0.0)
@@ -306,6 +313,10 @@ def fused_report(fused, fb, f16, voxels_rank, voxels_all, n_row, n_col, per_laun
         "hbm_frac": hbm_gbps / HBM_PEAK_GBS,
     }
     derived, src = fused_sq_profile()
+    if live_valu:  # SQ_INSTS_VALU of this run's own fused launches (a child pass under rocprofv3 --pmc)
+        derived = {"valu_instructions_per_voxel_update": live_valu["wave_instructions_per_launch"] * 64.0 / per_launch,
+                   "lds_bank_conflict_share_of_lds_cycles": (derived or {}).get("lds_bank_conflict_share_of_lds_cycles")}
+        src = "measured in this run (rocprofv3 --pmc SQ_INSTS_VALU around %d fused launches of a child run)" % live_valu["launches"]
     if derived is not None:
         ipu = derived["valu_instructions_per_voxel_update"]
         achieved = rate * ipu  # lane-instructions/s: one lane executes `ipu` vector instructions per voxel-update
@@ -397,14 +408,14 @@ def main():
     os.dup2(2, 1)
 
     # roofline.traffic, measured live: child processes under the profiler, before this process initialises the GPU
-    live = None
+    live = {}
     under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
     if (args.live_traffic and args.gpus == 1 and args.workload == "c3" and args.slices == 0 and "RANK" not in os.environ
             and not under_profiler):
         tail = []
         for name in ("vx", "unroll", "tz", "lds_bytes", "variant", "order", "row_band", "stage_fusion"):
             tail += ["--" + name.replace("_", "-"), str(getattr(args, name))]
-        live = live_traffic(tail)
+        live = live_counters(tail, fused_batch=max(2, min(32, args.fused_batch)))
 
     import torch
 
@@ -732,12 +743,13 @@ def main():
     if rank == 0:
         traffic, traffic_src, traffic_sha = measured_traffic(w, world)
         traffic_live = False
-        if live is not None:
-            traffic, traffic_sha, traffic_live = live["bytes_per_launch"], kernel_source_sha16(), True
+        if live.get("traffic"):
+            lt = live["traffic"]
+            traffic, traffic_sha, traffic_live = lt["bytes_per_launch"], kernel_source_sha16(), True
             traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around child runs of "
                            "bench.py adding %d projections spread over the circle; FETCH_SIZE x 2048 (KiB, gfx950 half-count of wide "
                            "streaming reads) + WRITE_SIZE x 1024; per-launch min %.4g max %.4g bytes"
-                           % (live["launches"], live["min"], live["max"]))
+                           % (lt["launches"], lt["min"], lt["max"]))
         avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         algo_bytes = 8.0 * voxels_rank + (2.0 if f16 else 4.0) * n_row * n_col  # per launch: RMW of the slab + one projection pass
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -814,7 +826,7 @@ def main():
             out["roofline"]["frac_best_octant"] = algo_bytes / (best["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if fused is not None:
             per_launch = voxels_rank * fb
-            out["fused_extension"] = fused_report(fused, fb, f16, voxels_rank, voxels_all, n_row, n_col, per_launch)
+            out["fused_extension"] = fused_report(fused, fb, f16, voxels_rank, voxels_all, n_row, n_col, per_launch, live.get("fused_valu"))
             if fused.get("deferred_seconds"):
                 out["deferred_boundary"] = {
                     "what": "the headline's step unchanged -- one paris_hip_backproject call per projection -- with "

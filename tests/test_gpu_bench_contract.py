@@ -133,3 +133,25 @@ def test_one_rank_under_torchrun_with_rccl_prints_only_the_json_line():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["rank_placement"][0]["rank"] == 0 and "final_gather" not in d
+
+
+def test_config3_line_measures_its_traffic_in_the_run():
+    """The driver's own invocation is config 3 at N = 1: before it touches the GPU, bench.py runs child passes of itself under
+    `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU: one counter per pass) and reports the HBM bytes per launch and the
+    fused kernel's instructions per voxel-update measured there. A short job here (4 timed projections); the counter passes are
+    the real ones."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("no rocprofv3 on this box")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--batch", "4", "--spread", "1",
+                        "--cpu-budget", "0", "--cpu-c1", "0", "--fused-steps", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json_line(r.stdout)
+    rf = d["roofline"]
+    assert rf["traffic_measured_in_this_run"] is True and rf["traffic_is_of_this_kernel"] is True
+    # tiles no ray reaches are not moved: somewhat under the algorithmic bytes, never above them by more than counter noise
+    assert 0.85 < rf["traffic_over_algorithmic"] < 1.01
+    assert abs(rf["frac_dram"] - rf["traffic"] / (d["config"]["backproject_kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    assert d["config"]["whole_job"] is False and rf["launches_timed"] == 4
+    fr = d["fused_extension"]["roofline"]
+    assert fr["source"].startswith("measured in this run") and 15.0 < fr["valu_instructions_per_voxel_update"] < 40.0
