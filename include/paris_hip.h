@@ -388,8 +388,10 @@ int paris_hip_set_backproject_tuning(paris_hip_ctx* ctx, int vx, int unroll, int
 /* Shape of the slice kernel: waves (= slices per tile) x row groups per lane; (16,4) (16,2) (8,4) (8,2) (8,1),
  * (0,0) = default. */
 int paris_hip_set_backproject_slice_shape(paris_hip_ctx* ctx, int waves, int row_groups);
-/* Workgroup -> tile order (-1 default by volume shape, 0 x-fastest, 1 z-fastest, 5 one contiguous run of tiles per XCD, 8 one
- * band of y tiles per XCD swept x -> z -> y, 9 the same swept x -> y -> z, 12 order 8 in chunks of 256 slices) and the cache
+/* Workgroup -> tile order (-1 default by volume shape: 15 for planes beyond 1024^2, else 18, or 5 when the z tiles do not divide among the 8 XCDs; 0 x-fastest, 1 z-fastest, 5 one
+ * contiguous run of tiles per XCD, 8 one band of y tiles per XCD swept x -> z -> y, 9 the same swept x -> y -> z, 12 order 8 in chunks
+ * of 256 slices, 14 / 15 / 16 / 17 y tiles DEALT to the XCDs singly / in pairs / in fours / in eights, in shallow z chunks, 18 z tiles
+ * dealt to the XCDs) and the cache
  * policy of the volume stream (2 nontemporal loads with write-through nontemporal stores, 1 nontemporal, 0 plain, -1 library
  * default: plain for slabs that largely stay in the Infinity Cache between launches, up to 384 MiB, 2 for larger ones).
  * Performance only. */

@@ -375,6 +375,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + TY - 1u) / TY;
         g.ntz = (g.v_dim_z + g.tz - 1u) / g.tz;
+        settle_order(g);
         g.zchunk = chunk_tiles(g.order, g.tz, g.ntz, 64u);
         const uint32_t blocks = static_cast<uint32_t>(grid_blocks(g));
         hipLaunchKernelGGL((bp_tile_kernel<VX, UNROLL, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, g);
@@ -412,6 +413,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + 15u) / 16u;
         g.ntz = (g.v_dim_z + g.tz - 1u) / g.tz;
+        settle_order(g);
         g.zchunk = chunk_tiles(g.order, g.tz, g.ntz, 64u);
         hipLaunchKernelGGL((bp_column_state_kernel<FD>), dim3((g.v_dim_x + 255u) / 256u, g.v_dim_y), dim3(256), 0, stream, g,
                            const_cast<float*>(g.colstate));
@@ -429,6 +431,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + TY - 1u) / TY;
         g.ntz = (g.v_dim_z + NW - 1u) / NW;
+        settle_order(g);
         g.zchunk = chunk_tiles(g.order, NW, g.ntz, 64u);
         const uint32_t blocks = static_cast<uint32_t>(grid_blocks(g));
         const uint32_t lds_bytes = g.lds_floats * sizeof(float);
@@ -603,7 +606,8 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
         const uint32_t tz_min = std::min(tz, 8u);
         const uint64_t ntx = (v_dim_x + 63u) / 64u, nty = (v_dim_y + 3u) / 4u, ntz = (v_dim_z + tz_min - 1u) / tz_min;
         const uint64_t zchunk = chunk_tiles(12u, tz_min, static_cast<uint32_t>(ntz), 64u); // the deepest chunk pads most
-        const uint64_t padded = 8ull * (8u * ((nty + 63u) / 64u)) * ntx * zchunk * ((ntz + zchunk - 1u) / zchunk); // widest deal: groups of 8
+        const uint64_t padded = std::max<uint64_t>(8ull * (8u * ((nty + 63u) / 64u)) * ntx * zchunk * ((ntz + zchunk - 1u) / zchunk), // widest deal: groups of 8
+                                                   8ull * ntx * nty * ((ntz + 7u) / 8u));                                             // order 18
         if(padded > 0x7fffff00ull)
             return PARIS_HIP_ERROR_UNSUPPORTED;
     }
@@ -664,8 +668,9 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     g.lds_floats = (ctx->bp_lds_bytes ? ctx->bp_lds_bytes : LDS_BYTES_DEFAULT) / sizeof(float);
     g.tz = tz;
     // default mapping: beyond 1024^2 planes the y tiles are dealt to the XCDs in pairs, in shallow z chunks (order 15: round 3;
-    // rounds 1-2 ran a y band per XCD there, order 12), a contiguous run of tiles per XCD below (order 5)
-    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 15u : 5u);
+    // rounds 1-2 ran a y band per XCD there, order 12); below, z tiles dealt to the XCDs (order 18; volumes of fewer than 8 z tiles,
+    // and rounds 1-2: a contiguous run of tiles per XCD, order 5)
+    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 15u : 18u); // (18 falls back to 5 unless the z tiles divide among the XCDs: settle_order)
     g.store_sc1 = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) == 2 ? 1u : 0u;
     // 4-pixel staging needs every detector row to start 16-byte (half: 8-byte) aligned
     g.stage_vec4 = (ctx->bp_stage_vec4 != 0 && g.p_pitch % 4u == 0 && reinterpret_cast<uintptr_t>(d_p) % (4u * px) == 0)
@@ -1200,7 +1205,7 @@ extern "C" int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, in
 {
     if(int rc = paris_hip_flush_deferred(ctx))
         return rc;
-    if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5 || order == 8 || order == 9 || order == 12 || (order >= 14 && order <= 17)) || nontemporal < -1 || nontemporal > 2)
+    if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5 || order == 8 || order == 9 || order == 12 || (order >= 14 && order <= 18)) || nontemporal < -1 || nontemporal > 2)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     ctx->bp_order = order;
     ctx->bp_nt = nontemporal; // < 0: automatic (by slab size)

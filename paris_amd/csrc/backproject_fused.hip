@@ -191,6 +191,7 @@ namespace
         g.ntx = (g.v_dim_x + 63u) / 64u;
         g.nty = (g.v_dim_y + 4u * VX - 1u) / (4u * VX);
         g.ntz = (g.v_dim_z + TZ - 1u) / TZ;
+        settle_order(g);
         g.zchunk = chunk_tiles(g.order, TZ, g.ntz, 32u);
         const uint32_t blocks = static_cast<uint32_t>(grid_blocks(g));
         hipLaunchKernelGGL((bp_fused_kernel<VX, TZ, NT, FD>), dim3(blocks), dim3(256), g.lds_floats * sizeof(float), stream, fp);

@@ -156,9 +156,19 @@ namespace
             return 8ull * ((g.nty + 7u) / 8u) * g.ntx * g.ntz;
         if(g.order == 12u)
             return 8ull * ((g.nty + 7u) / 8u) * g.ntx * g.zchunk * ((g.ntz + g.zchunk - 1u) / g.zchunk);
-        if(g.order >= 14u)
+        if(g.order == 18u) // z tiles dealt: 8 XCDs x whole planes x rounds
+            return 8ull * g.ntx * g.nty * ((g.ntz + 7u) / 8u);
+        if(g.order >= 14u && g.order <= 17u)
             return 8ull * dealt_band(g.nty, g.order) * g.ntx * g.zchunk * ((g.ntz + g.zchunk - 1u) / g.zchunk);
         return total;
+    }
+
+    // Order 18 deals whole planes of tiles to the XCDs, one z tile each in turn: it balances only when the z tiles divide among the
+    // eight (17 z tiles would give one XCD three planes and the others two). Launchers call this after they know their ntz.
+    inline void settle_order(BpParams& g)
+    {
+        if(g.order == 18u && (g.ntz % 8u != 0u))
+            g.order = 5u;
     }
 
     // z tiles per chunk of the chunked orders, never more z tiles than the volume has (a shallow slab would otherwise launch up
@@ -169,8 +179,7 @@ namespace
     // (profiles/r03_ab_tile_order.txt): `deep` slices for them (64 for the tile kernel, 32 = one tile for the fused kernel).
     inline uint32_t chunk_tiles(uint32_t order, uint32_t tz, uint32_t ntz, uint32_t deep)
     {
-        static const uint32_t forced = [] { const char* e = std::getenv("PARIS_BP_ZCHUNK_SLICES"); return e ? static_cast<uint32_t>(std::atoi(e)) : 0u; }(); // experiments
-        const uint32_t slices = forced ? forced : (order >= 14u ? deep : 256u);
+        const uint32_t slices = order >= 14u ? deep : 256u;
         return std::min(std::max(1u, slices / std::max(1u, tz)), std::max(1u, ntz));
     }
 
@@ -215,6 +224,7 @@ namespace
     //   8: XCD k owns a band of y tiles; x fastest, then z, then y inside the band
     //   9: XCD k owns a band of y tiles; x fastest, then y, then z inside the band
     //  12: order 8 chunk by chunk of 256 slices (deep volumes)
+    //  18: z tiles dealt round-robin to the XCDs (XCD k owns z tiles k, k + 8, ...), x fastest, then y
     //  14: order 12 with y tiles dealt round-robin to the XCDs (XCD k owns y tiles k, k + 8, ...); 15, 16, 17: dealt in groups of 2, 4, 8
     __device__ __forceinline__ bool tile_of_block(const BpParams& g, uint32_t b, uint32_t& bx, uint32_t& by, uint32_t& bz)
     {
@@ -243,7 +253,22 @@ namespace
             by = xcd * band + yb;
             return yb < band && by < g.nty;
         }
-        if(g.order >= 14u)
+        if(g.order == 18u)
+        {
+            // z tiles dealt to the XCDs: XCD k owns z tiles k, k + 8, ...; x runs fastest, then y (whole planes of tiles). The default
+            // for planes up to 1024^2 since round 3: order 5 gives every XCD a contiguous eighth of the depth there, so the slices
+            // above / below the cone -- skipped -- all belong to the first and the last XCD, which then finish early. 1024^3, three
+            // interleaved rounds on one device: 0.7458 -> 0.7529 of the HBM peak, fused kernel 1799 -> 1825 GVox/s (groups of 2 or
+            // 4 z tiles: slower; profiles/r03_ab_zdeal.txt).
+            const uint32_t xcd = b % 8u;
+            uint32_t r = b / 8u;
+            bx = r % g.ntx;
+            r /= g.ntx;
+            by = r % g.nty;
+            bz = (r / g.nty) * 8u + xcd;
+            return bz < g.ntz;
+        }
+        if(g.order >= 14u && g.order <= 17u)
         {
             // order 12 with the y tiles DEALT to the XCDs instead of banded. Order 14: XCD k owns y tiles k, k + 8, k + 16, ...;
             // order 15 deals pairs (XCD k owns y tiles 2k, 2k + 1, 2k + 16, 2k + 17, ...), 16 and 17 groups of 4 and 8. x runs

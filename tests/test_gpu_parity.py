@@ -478,12 +478,14 @@ def test_backproject_every_kernel_shape_bit_exact(be, oracle, tuning):
     assert_bit_equal(got, want)
 
 
-@pytest.mark.parametrize("order", [0, 1, 5, 8, 9, 12])
-@pytest.mark.parametrize("tz,dims", [(8, (300, 150, 200)), (16, (70, 260, 136)), (3, (45, 40, 72))])
+@pytest.mark.parametrize("order", [0, 1, 5, 8, 9, 12, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("tz,dims", [(8, (300, 150, 200)), (16, (70, 260, 136)), (3, (45, 40, 72)), (8, (128, 150, 200))])
 def test_backproject_every_tile_order_bit_exact(be, oracle, order, tz, dims):
     """Every workgroup -> tile mapping of the tile kernel and of the fused kernel (x / z fastest, a contiguous run per XCD,
-    a y band per XCD swept x -> z -> y, x -> y -> z, and in chunks of 256 slices) covers every voxel exactly once: volumes
-    whose tile counts are not multiples of 8 (the XCD count) in y, deeper than one 256-slice chunk at tile depth 8, with a
+    a y band per XCD swept x -> z -> y, x -> y -> z, and in chunks of 256 slices; round 3: y tiles dealt to the XCDs singly, in
+    pairs, fours and eights in shallow z chunks, z tiles dealt to the XCDs) covers every voxel exactly once: volumes
+    whose tile counts are not multiples of 8 (the XCD count) or of the deal's group in y, deeper than one chunk, 16 z tiles (what
+    order 18 needs to be used: it falls back to order 5 unless the z tiles divide among the XCDs), with a
     slab offset; bit-identical to the oracle through single launches and through one fused launch."""
     g = (96, 80, 0.2, 0.25, -2.5, 1.25, 150, 250, 40.0)
     det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
@@ -1751,7 +1753,7 @@ def test_backproject_random_geometries_bit_exact(be, oracle, seed):
     # volumes are small: without this the band orders 8 / 9 / 12 and shallow tiles would only be fuzzed at full size)
     forced = seed % 2 == 1
     if forced:
-        be.set_backproject_order(int(rng.choice([0, 1, 5, 8, 9, 12])), -1)
+        be.set_backproject_order(int(rng.choice([0, 1, 5, 8, 9, 12, 14, 15, 16, 17, 18])), -1)
         be.set_backproject_tuning(tz=int(rng.choice([2, 5, 8, 16])))
     try:
         d_v = be.make_volume_device(dims[2], dims[1], dims[0])
