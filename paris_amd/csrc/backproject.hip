@@ -809,9 +809,7 @@ int paris_hip_launch_deferred(paris_hip_ctx* ctx)
     if(ctx == nullptr || ctx->defer_count == 0)
         return PARIS_HIP_SUCCESS;
     const uint32_t n = ctx->defer_count;
-    ctx->defer_count = 0; // first: batch_impl may fall back to single launches, which must not be deferred again
     const uint32_t depth = ctx->defer_depth;
-    ctx->defer_depth = 1;
     const uint32_t half = ctx->defer_half;
     const char* ring = reinterpret_cast<const char*>(ctx->defer_ring) + static_cast<size_t>(half) * ctx->defer_slots * ctx->defer_pitch * ctx->defer_dim_y;
     // beside the caller's next calls, on the ctx's second stream -- unless the caller wants every call complete on return, or is
@@ -840,6 +838,8 @@ int paris_hip_launch_deferred(paris_hip_ctx* ctx)
         PARIS_HIP_TRY(hipStreamWaitEvent(ctx->bp_stream, ctx->bp_ring_ready, 0));
         ctx->stream = ctx->bp_stream;
     }
+    ctx->defer_count = 0; // before the launch: batch_impl may fall back to single launches, which must not be deferred again
+    ctx->defer_depth = 1;
     const int rc = batch_impl(ctx, ring, ctx->defer_f16, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
                               ctx->defer_dim_y, ctx->key_v, ctx->key_dims[0], ctx->key_dims[1], ctx->key_dims[2], ctx->key_dims[3],
                               &ctx->key_det, &ctx->key_vol, ctx->key_enable_roi, &ctx->key_roi, ctx->defer_sin.data(),
