@@ -144,7 +144,16 @@ int main(int argc, char** argv)
         be::detail::runtime_check(paris_hip_set_stage_fusion(ctx, PARIS_HIP_STAGE_FUSION), "fusion");
         const auto deferred = run(det, vol_geo, slab_z, n_proj, frames, true);
 
+        // run 3: the same with the fused launches on the ctx's second stream (paris_hip_set_backproject_overlap; off by default):
+        // every observer must also join the two streams
+        be::detail::runtime_check(paris_hip_set_backproject_overlap(ctx, 1), "overlap");
+        const auto overlapped = run(det, vol_geo, slab_z, n_proj, frames, true);
+        be::detail::runtime_check(paris_hip_set_backproject_overlap(ctx, 0), "overlap");
+
         bool ok = same(plain.weighted, deferred.weighted, "weighted projection read before its filter");
+        ok = same(plain.a_mid, overlapped.a_mid, "slab A read in the middle of a deferred group, launches on the second stream") && ok;
+        ok = same(plain.a_end, overlapped.a_end, "slab A at the end, launches on the second stream") && ok;
+        ok = same(plain.b_end, overlapped.b_end, "slab B at the end, launches on the second stream") && ok;
         ok = same(plain.a_mid, deferred.a_mid, "slab A read in the middle of a deferred group") && ok;
         ok = same(plain.a_end, deferred.a_end, "slab A at the end") && ok;
         ok = same(plain.b_end, deferred.b_end, "slab B at the end (calls alternating between the slabs)") && ok;

@@ -88,10 +88,12 @@ def test_flush_rules_at_config3_size():
     """the deferred boundary (16 backproject() calls per fused launch) and the held-back weight() through the
     C++ mirror paris::hip on the 2048^2 detector / 2048^3 grid of BASELINE config 3, with every observer that must flush
     interleaved (copy_d2h in the middle of a group, calls alternating between two slabs, make / free of other buffers,
-    synchronize, a projection read between weight and filter): every read-back equals the one-launch-per-call run bit for bit."""
+    synchronize, a projection read between weight and filter): every read-back equals the one-launch-per-call run bit for bit;
+    round 3: once more with paris_hip_set_backproject_overlap(1) (fused launches on a second stream that every observer joins)."""
     exe = os.path.join(ROOT, "paris_amd", "host", "demo", "paris_hip_flush_rules")
     if not os.path.exists(exe):
         pytest.fail("%s missing: run __graft_entry__.build()" % exe)
     r = subprocess.run([exe, "64", "40"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "flush rules ok" in r.stdout and r.stdout.count("equal bit for bit") == 4
+    # four read-backs of the deferred run + three of the run with the fused launches on the ctx's second stream
+    assert "flush rules ok" in r.stdout and r.stdout.count("equal bit for bit") == 7 and r.stdout.count("second stream") == 3
