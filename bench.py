@@ -36,6 +36,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# BASELINE.md section 3 asks for OMP_PROC_BIND=spread OMP_PLACES=cores on the CPU leg. Measured on the GPU box (a 16-core cgroup
+# quota on a 256-CPU host, profiles/r03_ab_cpu_binding.txt) that binding costs the oracle 7.5x (0.19 against 1.46 GVox/s for the
+# whole config-1 job), so the leg runs unbound unless the caller's environment binds it; "omp" in the line records what was used
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 HBM_COPY_GBS = 6290.0  # same guide: measured copy rate (tools/membench.hip: 6.67 TB/s linear nontemporal read-modify-write here)
 # a slab of up to ~192 MiB stays in the 256 MiB Infinity Cache between launches: its read-modify-write is bounded by the cache, not
@@ -202,10 +206,15 @@ def cpu_baseline(w, budget_s):
     t_path = t_b + (t_w + t_f) * share
     return {
         "value": updates / t_path / 1e9, "unit": "GVoxel-updates/s", "cores": cores, "kind": "port",
+        "per_core": updates / t_path / 1e9 / cores, "omp": omp_binding(),
         "sample": "%s geometry, %d central slices (z %d..%d) x %d projections: backproject %.2f s + %d/%d of "
                   "weight %.2f s and filter %.2f s" % (w["name"], slices, z0, z0 + slices - 1, n, t_b, slices, dz,
                                                        t_w, t_f),
     }
+
+
+def omp_binding():
+    return {"proc_bind": os.environ.get("OMP_PROC_BIND"), "places": os.environ.get("OMP_PLACES")}
 
 
 def cpu_model():
@@ -264,7 +273,7 @@ def cpu_baseline_c1():
     updates = float(dx) * dy * dz * n_proj
     return {
         "value": updates / t_b / 1e9, "unit": "GVoxel-updates/s", "cores": cores, "kind": "port",
-        "per_core": updates / t_b / 1e9 / cores, "cpu_model": cpu_model(),
+        "per_core": updates / t_b / 1e9 / cores, "cpu_model": cpu_model(), "omp": omp_binding(),
         "backproject_s": t_b, "weight_s": t_w, "filter_s": t_f,
         "whole_path_value": updates / (t_b + t_w + t_f) / 1e9,
         "volume_checksum": float(vol.sum(dtype=np.float64)),

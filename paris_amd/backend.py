@@ -160,7 +160,8 @@ class Backend:
         """Adopts device memory allocated elsewhere as a volume. The library knows nothing about its contents, so every
         addition is performed (paris_hip_set_backproject_skip_invalid does not apply) unless the caller vouches with clean=True
         that it holds no -0 right now (e.g. torch.zeros) and will call volume_mark_dirty before writing anything but zeros into
-        it; clean=False withdraws an earlier promise for the range."""
+        it; clean=False withdraws an earlier promise for the range; clean="scan" lets the device look for -0 once
+        (paris_hip_volume_scan_clean) and skip when there is none, under the same duty."""
         v = Volume(ptr, dim_x, dim_y, dim_z, off, on_device=True, owner=owner)
         try:
             import weakref
@@ -171,6 +172,10 @@ class Backend:
             self.volume_mark_clean(v)
         elif clean is False:
             self.volume_mark_dirty(v)
+        elif clean == "scan":
+            self.volume_scan_clean(v)
+        elif clean is not None:
+            raise ValueError("clean must be None, True, False or 'scan'")
         return v
 
     def volume_mark_dirty(self, v):
@@ -180,6 +185,13 @@ class Backend:
     def volume_mark_clean(self, v):
         """the caller vouches that the volume holds no -0 right now (paris_hip_volume_mark_clean)"""
         check(self._L.paris_hip_volume_mark_clean(self._ctx, v.ptr, 4 * v.dim_x * v.dim_y * v.dim_z), "paris_hip_volume_mark_clean")
+
+    def volume_scan_clean(self, v):
+        """reads the volume once on the device; lists it as clean when it holds no -0; returns the number of -0 found"""
+        n = C.c_uint64(0)
+        check(self._L.paris_hip_volume_scan_clean(self._ctx, v.ptr, 4 * v.dim_x * v.dim_y * v.dim_z, C.byref(n)),
+              "paris_hip_volume_scan_clean")
+        return int(n.value)
 
     def memset_volume(self, v):
         check(self._L.paris_hip_memset_volume(self._ctx, v.ptr, v.dim_x, v.dim_y, v.dim_z), "paris_hip_memset_volume")

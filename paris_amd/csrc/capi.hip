@@ -464,6 +464,84 @@ extern "C" int paris_hip_volume_mark_clean(paris_hip_ctx* ctx, const void* d_ptr
     return PARIS_HIP_SUCCESS;
 }
 
+namespace
+{
+    // counts the words of w[0, n) that are the bit pattern of -0.0f: the 16-byte aligned body as uint4 loads (read once, not
+    // kept in the caches), the few words before and after it one by one
+    __global__ void __launch_bounds__(256) count_negative_zero_kernel(const uint32_t* __restrict__ w, size_t n, unsigned long long* __restrict__ out)
+    {
+        const size_t head = min(n, static_cast<size_t>(((16u - static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w) & 15u)) & 15u) / 4u));
+        const size_t n4 = (n - head) / 4u;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* __restrict__ body = reinterpret_cast<const u32x4*>(w + head);
+        uint32_t c = 0;
+        for(size_t i = static_cast<size_t>(blockIdx.x) * 256u + threadIdx.x; i < n4; i += static_cast<size_t>(gridDim.x) * 256u)
+        {
+            const u32x4 q = __builtin_nontemporal_load(body + i);
+            c += (q.x == 0x80000000u) + (q.y == 0x80000000u) + (q.z == 0x80000000u) + (q.w == 0x80000000u);
+        }
+        if(blockIdx.x == 0)
+        {
+            const size_t tail0 = head + 4u * n4;
+            if(threadIdx.x < head)
+                c += w[threadIdx.x] == 0x80000000u;
+            if(tail0 + threadIdx.x < n)
+                c += w[tail0 + threadIdx.x] == 0x80000000u;
+        }
+        if(c != 0)
+            atomicAdd(out, static_cast<unsigned long long>(c));
+    }
+}
+
+// Extension (include/paris_hip.h): looks for -0 in [d_ptr, d_ptr + bytes) once, on the device, and lists the range as clean when
+// there is none -- the way to let memory of unknown history (a tensor of the caller's) skip the tiles no ray reaches
+extern "C" int paris_hip_volume_scan_clean(paris_hip_ctx* ctx, const void* d_ptr, size_t bytes, uint64_t* negative_zeros)
+{
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
+    if(int rc = paris_hip_bind(ctx))
+        return rc;
+    if(d_ptr == nullptr || bytes == 0 || bytes % sizeof(float) != 0 || reinterpret_cast<uintptr_t>(d_ptr) % sizeof(float) != 0)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    hipPointerAttribute_t attr{};
+    if(hipPointerGetAttributes(&attr, d_ptr) != hipSuccess || attr.type != hipMemoryTypeDevice)
+    {
+        (void)hipGetLastError();
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    }
+    unsigned long long* d_count = nullptr;
+    PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_count), sizeof(unsigned long long)));
+    const size_t n = bytes / sizeof(float);
+    const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>(16384u, std::max<size_t>(1u, (n / 4u + 255u) / 256u)));
+    unsigned long long count = 0;
+    hipError_t err = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream);
+    if(err == hipSuccess)
+    {
+        hipLaunchKernelGGL(count_negative_zero_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_ptr), n, d_count);
+        err = hipGetLastError();
+    }
+    if(err == hipSuccess)
+        err = hipMemcpyAsync(&count, d_count, sizeof(count), hipMemcpyDeviceToHost, ctx->stream);
+    if(err == hipSuccess)
+        err = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_count);
+    PARIS_HIP_TRY(err);
+    if(negative_zeros != nullptr)
+        *negative_zeros = count;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_ptr);
+    if(count != 0)
+    {
+        erase_overlapping(ctx->clean_volumes, a, bytes); // whatever was promised about the range before, it holds a -0 now
+        return PARIS_HIP_SUCCESS;
+    }
+    if(!paris_hip_volume_is_clean(ctx, d_ptr, bytes))
+    {
+        erase_overlapping(ctx->clean_volumes, a, bytes);
+        ctx->clean_volumes[a] = bytes;
+    }
+    return PARIS_HIP_SUCCESS;
+}
+
 extern "C" int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, float** d_ptr)
 {
     if(int rc = paris_hip_bind(ctx))

@@ -44,6 +44,9 @@ def test_single_gpu_line():
     assert fr is None or (fr["bound"] == "valu_issue" and abs(fr["frac"] - fr["achieved"] / fr["peak"]) < 1e-12)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["cpu_model"]
+    # the thread binding the leg ran under is on the line (unbound unless the caller's environment binds it)
+    assert cb["omp"] == {"proc_bind": os.environ.get("OMP_PROC_BIND"), "places": os.environ.get("OMP_PLACES")}
+    assert abs(cb["per_core"] * cb["cores"] - cb["value"]) < 1e-9 * cb["value"]
     # the skip-off leg: one more step (120 launches here) with every tile read and written; the DRAM-side fraction needs a
     # committed PMC profile of this workload (none for config 1: null)
     assert rf["without_skip_launches"] == 120 and rf["frac_without_skip"] > 0 and rf["kernel_ms_without_skip"] > 0
@@ -76,6 +79,27 @@ def test_two_rank_rehearsal():
     assert [e["rank"] for e in pr] == [0, 1] and [e["slab"] for e in pr] == [[0, 128], [128, 128]]
     assert all(e["launches"] == 360 and 0 < e["kernel_ms_min"] <= e["kernel_ms_mean"] <= e["kernel_ms_max"] for e in pr)
     assert len(set(d["roofline"]["kernel_source_sha16_by_rank"])) == 1 and len(set(e["library_sha16"] for e in pr)) == 1
+
+
+def test_four_rank_rehearsal_with_a_ragged_split():
+    """Four ranks on the one GPU (gloo), a volume whose 256 slices split evenly but whose 7-projection batch does not divide by
+    the rank count: every rank reports its own slab and statistics, the sharded filter and the plain run agree."""
+    def run(extra):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload",
+                            "c1", "--steps", "1", "--warmup", "0", "--batch", "7", "--dist-backend", "gloo", "--device", "0",
+                            "--fused-steps", "0"] + extra, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return last_json_line(r.stdout)
+    plain, sharded = run([]), run(["--filter-shard", "1"])
+    pr = plain["config"]["per_rank"]
+    assert [e["rank"] for e in pr] == [0, 1, 2, 3] and [e["slab"] for e in pr] == [[64 * r, 64] for r in range(4)]
+    assert plain["n_gpus"] == 4 and plain["config"]["slab_per_gpu"] == [256, 256, 64]
+    assert plain["final_gather"]["rccl_ranks_seen"] == 4 and len(plain["final_gather"]["slab_checksums"]) == 4
+    assert sharded["final_gather"]["slab_checksums"] == plain["final_gather"]["slab_checksums"]
 
 
 def test_two_rank_rehearsal_gathers_slabs():

@@ -1569,6 +1569,72 @@ def test_volume_mark_dirty_and_clean(be, oracle):
     be.volume_mark_dirty(w)
 
 
+def test_volume_scan_clean(be, oracle):
+    """paris_hip_volume_scan_clean (ADVICE r02, the device scan for sign-bit zeros): memory of unknown history is read once;
+    without a -0 it is listed as clean (tiles no ray reaches are then left alone: shown by the -0 a later unannounced write
+    leaves behind), with one it takes every addition and the count is exact -- including words before and after the 16-byte
+    aligned body of the range."""
+    import torch
+    g = (64, 48, 0.4, 0.4, 1.5, -2.0, 200, 150, 23.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    dims = (192, 72, 95)   # odd row length: with the one-word offset below neither end of the range is 16-byte aligned
+    dz, dy, dx = dims
+    l_vx = float(nat.l_vx_x)
+    vg = B.VolumeGeometry(dx, dy, dz, l_vx * 1.1, l_vx * 2.6, l_vx * 1.7)
+    ovg = oracle.VolumeGeometry(dx, dy, dz, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    projs = [oracle.lcg_projection(64, 48, i) - np.float32(0.5) for i in range(4)]
+    want_zero = oracle_backproject_all(oracle, projs, odet, ovg, dims)
+    n = dx * dy * dz
+    start = np.zeros(n, np.float32)
+    marks = [0, 1, 2, 5, n // 2, n - 3, n - 2, n - 1]
+    start[marks] = np.float32(-0.0)
+    start[7] = np.float32(-1.5)        # sign bit set but not a zero: not counted
+    want_up = start.reshape(dims).copy()
+    for i, p in enumerate(projs):
+        s, c, ds, dt = oracle.backproject_constants(odet, i)
+        oracle.backproject(want_up, p, 0, odet, ovg, s, c, ds, dt, None)
+    dev = torch.device("cuda", 0)
+
+    def add_all(d_v):
+        for i, p in enumerate(projs):
+            d_p = to_device(be, p, idx=i)
+            B.backproject(be, d_p, d_v, 0, det, vg, False, False, None)
+            be.free(d_p)
+        return volume_to_host(be, d_v)
+
+    be.set_backproject_skip_invalid(True)
+    pool = torch.zeros(n + 8, dtype=torch.float32, device=dev)
+    t = pool[1:n + 1]
+    assert t.data_ptr() % 16 == 4
+    torch.cuda.synchronize()
+    # (1) nothing found: listed as clean, same bits as the oracle from zero ...
+    w = be.wrap_volume(t.data_ptr(), dx, dy, dz, owner=pool)
+    assert be.volume_scan_clean(w) == 0
+    assert_bit_equal(add_all(w), want_zero)
+    # ... and the range really is skipped from now on: an unannounced write of -0 survives where no ray reaches
+    t.copy_(torch.from_numpy(start).to(dev))
+    torch.cuda.synchronize()
+    got = add_all(w)
+    assert np.signbit(got[got == 0]).sum() > 0
+    # (2) the same values scanned: every -0 counted (the -1.5 is none), the promise withdrawn, every addition made
+    t.copy_(torch.from_numpy(start).to(dev))
+    torch.cuda.synchronize()
+    assert be.volume_scan_clean(w) == len(marks)
+    assert_bit_equal(add_all(w), want_up)
+    # (3) through wrap_volume; a range that is no whole number of floats or no device memory is refused
+    t.zero_()
+    torch.cuda.synchronize()
+    assert_bit_equal(add_all(be.wrap_volume(t.data_ptr(), dx, dy, dz, owner=pool, clean="scan")), want_zero)
+    L = be._L
+    assert L.paris_hip_volume_scan_clean(be._ctx, t.data_ptr(), 4 * n - 2, None) == 10001  # PARIS_HIP_ERROR_INVALID_ARGUMENT
+    host = np.zeros(64, np.float32)
+    assert L.paris_hip_volume_scan_clean(be._ctx, host.ctypes.data, host.nbytes, None) == 10001  # PARIS_HIP_ERROR_INVALID_ARGUMENT
+    with pytest.raises(ValueError):
+        be.wrap_volume(t.data_ptr(), dx, dy, dz, owner=pool, clean="maybe")
+    be.volume_mark_dirty(w)
+
+
 def test_ctx_destroy_runs_pending_work_only_into_its_own_volumes(oracle):
     """projections still deferred when the ctx is destroyed are run into a volume the ctx allocated (and has
     not freed), and dropped for any other address -- the library cannot know whether foreign memory still belongs to the
