@@ -372,8 +372,8 @@ def main():
     ap.add_argument("--order", type=int, default=-1, help="workgroup -> tile order of the backprojection kernel (-1: the library's default)")
     ap.add_argument("--fused-steps", type=int, default=8, help="extra steps with the fused multi-projection kernel, "
                     "reported as fused_extension next to the headline (0 disables); the steps are spread over the circle")
-    ap.add_argument("--fused-batch", type=int, default=16, help="projections per fused launch in fused_extension and "
-                    "deferred_boundary (2..32; the headline step keeps single-projection launches)")
+    ap.add_argument("--fused-batch", type=int, default=48, help="projections per fused launch in fused_extension and "
+                    "deferred_boundary (2..64; the headline step keeps single-projection launches)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of the N > 1 path "
                     "with several ranks sharing one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default: LOCAL_RANK)")
@@ -424,7 +424,7 @@ def main():
         tail = []
         for name in ("vx", "unroll", "tz", "lds_bytes", "variant", "order", "row_band", "stage_fusion"):
             tail += ["--" + name.replace("_", "-"), str(getattr(args, name))]
-        live = live_counters(tail, fused_batch=max(2, min(32, args.fused_batch)))
+        live = live_counters(tail, fused_batch=max(2, min(64, args.fused_batch)))
 
     import torch
 
@@ -488,7 +488,7 @@ def main():
     batch = args.batch if args.batch > 0 else -(-n_proj // max(1, args.steps))
     gen = torch.Generator(device=dev)
     gen.manual_seed(12345)  # every rank holds the same projection stack (north star: "each GPU holding the full projection stack")
-    fb = max(2, min(32, args.fused_batch))
+    fb = max(2, min(64, args.fused_batch))
     nb = max(16, fb)  # work slots and distinct raw frames; a step cycles through them (stream order makes the reuse safe)
     raw = torch.rand((nb, n_col, n_row), generator=gen, device=dev, dtype=torch.float32)
     work = torch.empty_like(raw)

@@ -267,7 +267,7 @@ int paris_hip_backproject_f16(paris_hip_ctx* ctx, const uint16_t* d_p, size_t p_
                               const paris_region_of_interest* roi, float sin_phi, float cos_phi, float delta_s,
                               float delta_t);
 
-/* Extension (no reference counterpart): backprojects n_proj projections per launch (fused kernel, up to 32 per
+/* Extension (no reference counterpart): backprojects n_proj projections per launch (fused kernel, up to 64 per
  * launch, more are split); projection i is at d_p + i * p_stride_bytes. Every voxel's sum is accumulated in
  * projection order in registers, so the result is bit-identical to n_proj successive paris_hip_backproject calls
  * while the volume is read and written once per launch: 8 / n_proj bytes of HBM traffic per voxel-update. Any volume
@@ -299,7 +299,7 @@ int paris_hip_backproject_batch_f16(paris_hip_ctx* ctx, const uint16_t* d_p, siz
  * projections (call paris_hip_flush first), and paris_hip_ctx_destroy runs what is still pending only into a volume that
  * paris_hip_malloc_volume of this ctx allocated and paris_hip_free has not taken back (pending projections of any other volume
  * are dropped: the library cannot know whether that address still belongs to the caller). Depth 1 (the
- * default) is immediate execution. The C++ mirror paris::hip enables depth 16, so PARIS's unchanged per-projection loop
+ * default) is immediate execution. The C++ mirror paris::hip enables depth 48, so PARIS's unchanged per-projection loop
  * (src/main.cpp:98-105) runs at the fused kernel's rate. */
 int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t depth);
 int paris_hip_flush(paris_hip_ctx* ctx);

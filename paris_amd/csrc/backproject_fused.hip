@@ -70,9 +70,9 @@ namespace
         // isolation when no source is a scalar register, tools/pkbench.hip -- was measured: no gain in this instruction mix.)
         const char* base = static_cast<const char*>(fp.g.proj);
         const size_t px = g.proj_f16 ? 2u : 4u;
-        // the detector boxes of all projections of this tile, 16 per wave at once (waves 0 and 1: FUSED_MAX = 32)
+        // the detector boxes of all projections of this tile, 16 per wave at once (four waves: FUSED_MAX = 64)
         __shared__ int box_tab[FUSED_MAX * BOX_WORDS];
-        if(wave * 16u < fp.n_proj && wave < 2u)
+        if(wave * 16u < fp.n_proj)
             tile_boxes_to_lds(g, fp.sin_phi, fp.cos_phi, wave * 16u, fp.n_proj, k0, k1, l0, l1, m0, m1, lane, g.lds_floats, FIXED_STRIDE, box_tab);
         for(uint32_t p = 0; p < fp.n_proj; ++p)
         {

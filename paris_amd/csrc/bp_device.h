@@ -884,7 +884,7 @@ namespace
     // and written once per batch: 8 / n_proj bytes per voxel-update. With the HBM term gone the kernel is bound by
     // vector ALU issue (about 40 instructions per voxel-update plus the per-projection column setup).
     // --------------------------------------------------------------------------------------------
-    constexpr int FUSED_MAX = 32;
+    constexpr int FUSED_MAX = 64;
 
     struct FusedParams
     {

@@ -1,6 +1,6 @@
 // The deferred plugin boundary at full size, through the C++ mirror.
 //
-// paris::hip defers backproject() calls (16 per fused launch) and holds weight() back for the filter that follows
+// paris::hip defers backproject() calls (PARIS_HIP_BACKPROJECT_DEFERRAL per fused launch) and holds weight() back for the filter that follows
 // (stage fusion). Both are invisible only if every way PARIS can observe device data first runs what is pending
 // (include/paris_hip.h, paris_hip_set_backproject_deferral / paris_hip_set_stage_fusion). This program drives the call
 // sequence of src/main.cpp:98-105 on the geometry of BASELINE config 3 (2048^2 detector, the 2048^3 grid) into two

@@ -15,7 +15,7 @@
 #define PARIS_AMD_HOST_HIP_BACKEND_H_
 
 #ifndef PARIS_HIP_BACKPROJECT_DEFERRAL
-#define PARIS_HIP_BACKPROJECT_DEFERRAL 16
+#define PARIS_HIP_BACKPROJECT_DEFERRAL 48
 #endif
 // 1 (default): weight() is held back and rides along in the load of the apply_filter() call that follows (one launch per
 // weight / filter pair of src/main.cpp:102-103; paris_hip_set_stage_fusion). 0: one launch per call.

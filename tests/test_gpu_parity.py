@@ -915,9 +915,10 @@ def test_make_subvolume_information(be):
                                                          (33, 8, 4096, 0, 82), (9, 0, 0, 4, 82), (9, 8, 0, 4, 82), (9, 0, 0, 1, 82),
                                                          (9, 0, 0, 0, 81), (7, 0, 1024, 0, 79), (9, 0, 0, 0, 80),
                                                          (9, 0, 0, 2, 82), (9, 8, 0, 2, 82), (33, 16, 2048, 2, 80), (9, 16, 0, 1, 82),
-                                                         (9, 32, 0, 1, 81), (5, 16, 1024, 0, 82)])
+                                                         (9, 32, 0, 1, 81), (5, 16, 1024, 0, 82),
+                                                         (64, 0, 0, 0, 82), (65, 8, 0, 2, 82), (70, 0, 0, 1, 81), (49, 16, 2048, 4, 82)])
 def test_backproject_fused_batch_bit_exact(be, oracle, n_proj, tz, lds_bytes, vx, x2):
-    """paris_hip_backproject_batch's fused kernel (n_proj projections per launch, split at 32) adds the projections
+    """paris_hip_backproject_batch's fused kernel (n_proj projections per launch, split at 64) adds the projections
     to every voxel in projection order: bit-identical to the oracle's sequential loop. Partial tiles in x, y, z;
     ROI and slab offset; every tile depth (8, 16, 32); an LDS budget that forces the global tap path; every lane width (default:
     one voxel per lane, 32 slices; 2 and 4 voxels on request where the rows are aligned for them)."""
