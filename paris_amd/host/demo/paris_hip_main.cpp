@@ -4,7 +4,7 @@
 //
 //   paris.hip --geometry geo.ini --input <dir> --output <dir> [--name vol] [--angles file] [--quality q]
 //             [--roi --roi-x1 a --roi-x2 b --roi-y1 c --roi-y2 d --roi-z1 e --roi-z2 f]
-//             [--slabs n] [--devices n] [--f16] [--no-row-band] [--batch n] [--drain-chunk-kib n]
+//             [--slabs n] [--devices n] [--f16] [--no-row-band] [--batch n] [--drain-chunk-kib n] [--share-frames 0|1]
 //             [--window ramp|shepp-logan]
 // geo.ini: key=value lines for n_row n_col l_px_row l_px_col delta_s delta_t d_so d_od delta_phi (:83-91).
 #include <cstdio>
@@ -77,7 +77,7 @@ int main(int argc, char** argv)
             {
                 std::printf("paris.hip --geometry geo.ini --input <dir of .his files> --output <dir> [--name vol] [--angles file] [--quality q]\n"
                             "          [--roi --roi-x1 a --roi-x2 b --roi-y1 c --roi-y2 d --roi-z1 e --roi-z2 f]\n"
-                            "          [--slabs n] [--devices n] [--f16] [--window ramp|shepp-logan] [--batch n] [--no-row-band]\n"
+                            "          [--slabs n] [--devices n] [--f16] [--window ramp|shepp-logan] [--batch n] [--no-row-band] [--share-frames 0|1]\n"
                             "          [--drain-chunk-kib n]\n"
                             "geo.ini: key=value lines for n_row n_col l_px_row l_px_col delta_s delta_t d_so d_od delta_phi\n"
                             "Reconstructs the HIS projections of <dir> (sorted by path) into <output>/<name>.ddbvf on all MI355X of the node.\n");
@@ -108,6 +108,7 @@ int main(int argc, char** argv)
                 else throw paris::stage_construction_error{"unknown filter window " + w};
             }
             else if(k == "--batch") po.batch = std::stoi(val());
+            else if(k == "--share-frames") po.share_frames = std::stoi(val());
             else if(k == "--drain-chunk-kib") po.drain_chunk_bytes = static_cast<std::size_t>(std::stoull(val())) << 10;
             else throw paris::stage_construction_error{"unknown option " + k};
         }
@@ -125,9 +126,12 @@ int main(int argc, char** argv)
         const auto r = paris::run(po);
         std::printf("volume %u x %u x %u (%d slab%s) -> %s in %.3f s\n", r.roi_geo.dim_x, r.roi_geo.dim_y, r.roi_geo.dim_z, r.info.num,
                     r.info.num == 1 ? "" : "s", r.output_file.c_str(), r.wall_s);
-        if(r.devices.size() > 1)
+        if(r.devices.size() > 1 && r.shared_source)
             std::printf("shared frame source: %llu frames read from the files for %llu frame requests of the device threads\n",
                         static_cast<unsigned long long>(r.frames_read), static_cast<unsigned long long>(r.frames_requested));
+        else if(r.devices.size() > 1)
+            std::printf("frame source: one stream per device thread, each reads its slab's detector rows (%.2f detectors' worth per pass)\n",
+                        r.rows_per_pass);
         for(const auto& s : r.skipped)
             std::printf("  skipped invalid file %s\n", s.c_str());
         for(const auto& d : r.devices)

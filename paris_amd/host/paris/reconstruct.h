@@ -57,6 +57,10 @@ namespace paris
         std::size_t drain_chunk_bytes = std::size_t{16} << 20;
         int window = PARIS_HIP_WINDOW_RAMP; // filter window (extension: PARIS_HIP_WINDOW_SHEPP_LOGAN; the reference has the ramp only)
         bool row_band = true; // f4: per slab, upload / weight / filter only the detector rows the slab can read
+        // several devices: 1 = the device threads of a pass share one read-once frame source (source.h: shared_frames), 0 = each reads
+        // the files through a stream of its own (only its slab's detector rows when row_band is on), -1 = decided by how many
+        // detector rows the slabs of a pass need between them (run())
+        int share_frames = -1;
     };
 
     // src/task.h:33-57
@@ -468,6 +472,8 @@ namespace paris
         subvolume_info info{};
         std::vector<device_report> devices;
         std::uint64_t frames_read = 0, frames_requested = 0; // several devices: frames converted from the files / frames handed to device threads
+        bool shared_source = false;   // several devices: the read-once shared frame source was used
+        double rows_per_pass = 0.0;   // several devices: detector rows the slabs of one pass need between them, in detectors
         std::vector<std::string> skipped;                  // several devices: invalid files skipped by the shared source
         int batch = 0; // frames per fused launch actually used (program_options::batch, halved until the slots fit the devices)
         double wall_s = 0;
@@ -510,16 +516,44 @@ namespace paris
 
         if(n_dev > 1) // :157-167
         {
+            // Where the frames come from. Every device thread needs every projection, but with the row band (f4) only the detector
+            // rows its slab can read: z-slabs of one pass over the queue need little more than one detector's worth of rows between
+            // them, and a stream per thread that reads and converts just its band does less work per frame than one whole-frame
+            // conversion plus a band copy per thread, with nothing shared to wait for (8 bands of a 2048^2 frame: 0.67 against
+            // 1.8 ms per frame on 8 cores, tools/shared_source_bench.py). Bands that overlap widely (no row band, thick cones, few
+            // rows: the pass would read the files more than twice over) are read once and shared instead.
+            const auto first_pass = std::min<std::uint32_t>(static_cast<std::uint32_t>(n_dev), static_cast<std::uint32_t>(r.info.num));
+            if(po.row_band && po.det_geo.n_col != 0)
+            {
+                std::uint64_t rows = 0;
+                for(std::uint32_t i = 0; i < first_pass; ++i)
+                {
+                    const bool last = i + 1u == static_cast<std::uint32_t>(r.info.num);
+                    std::uint32_t band_first = 0, band_count = po.det_geo.n_col;
+                    detail::rt(paris_hip_slab_row_band(&po.det_geo, &r.vol_geo, r.info.geo.dim_x, r.info.geo.dim_y,
+                                                       r.info.geo.dim_z + (last ? r.info.geo.remainder : 0u), i * r.info.geo.dim_z, po.enable_roi,
+                                                       &po.roi, &band_first, &band_count), "slab_row_band()");
+                    rows += band_count;
+                }
+                r.rows_per_pass = static_cast<double>(rows) / po.det_geo.n_col;
+            }
+            else
+                r.rows_per_pass = static_cast<double>(first_pass);
+            r.shared_source = po.share_frames < 0 ? r.rows_per_pass > 2.0 : po.share_frames != 0;
             frame_pool pool{n_dev, po.det_geo.n_row, po.det_geo.n_col}; // every HIS frame is read once per pass, not once per device
+            auto* shared = r.shared_source ? &pool : nullptr;
             auto futures = std::vector<std::future<device_report>>{};
             for(int d = 0; d < n_dev; ++d)
-                futures.emplace_back(std::async(std::launch::async, [&queue, &out, &po, &pool, d] { return reconstruct(queue, d, out, po, &pool); }));
+                futures.emplace_back(std::async(std::launch::async, [&queue, &out, &po, shared, d] { return reconstruct(queue, d, out, po, shared); }));
             for(auto& f : futures)
                 r.devices.push_back(f.get());
-            const auto st = pool.stats();
-            r.frames_read = st.produced + st.reread;
-            r.frames_requested = st.served + st.reread;
-            r.skipped = pool.skipped_files();
+            if(r.shared_source)
+            {
+                const auto st = pool.stats();
+                r.frames_read = st.produced + st.reread;
+                r.frames_requested = st.served + st.reread;
+                r.skipped = pool.skipped_files();
+            }
         }
         else
             r.devices.push_back(reconstruct(queue, 0, out, po)); // :169

@@ -256,12 +256,16 @@ namespace paris
     };
 
     // Read-once frame source shared by the device threads of one run. Every device needs every projection for its slab;
-    // the reference lets each device thread read the whole set again (src/main.cpp:93: a source per task). Here the
-    // thread that first asks for the k-th kept frame reads and converts it, once, into a buffer of a small ring; the
-    // other threads copy the rows they need (their slab's detector band) from that buffer. Correctness never depends on
-    // the ring: a consumer whose frame has already been recycled (it lags more than `capacity` frames behind, or it starts
-    // a later task) falls back to a frame_stream of its own, exactly today's behaviour. Frames, order, indices, angles and
-    // skipped files are frame_stream's.
+    // the reference lets each device thread read the whole set again (src/main.cpp:93: a source per task). Here every kept
+    // frame is read and converted once, into a buffer of a small ring, by whichever thread gets to it first; the other
+    // threads copy the rows they need (their slab's detector band) from that buffer. Frames are claimed in order, one
+    // thread each, and several are in production at a time: a thread whose own frame is still being read by another one
+    // does not sleep, it claims and reads the next unclaimed frame ahead (up to half a ring ahead of its own position), so
+    // N device threads convert N frames side by side instead of queueing behind one reader. Every producing thread reads
+    // through a stream of its own (the cursor's), stepping over the frames other threads produce without converting them.
+    // Correctness never depends on the ring: a consumer whose frame has already been recycled (it lags more than `capacity`
+    // frames behind, or it starts a later task) falls back to a frame_stream of its own, exactly the single-device behaviour.
+    // Frames, order, indices, angles and skipped files are frame_stream's.
     class shared_frames
     {
     public:
@@ -272,13 +276,16 @@ namespace paris
             std::uint64_t reread = 0;   // next() calls answered by a consumer's own fallback stream
         };
 
-        // per consumer and task: where it is in the sequence, and its fallback stream once it has needed one
+        // per consumer and task: where it is in the sequence, the stream it produces shared frames through, and its
+        // fallback stream once it has needed one
         class cursor
         {
             friend class shared_frames;
             std::uint64_t next_ = 0;
             std::unique_ptr<frame_stream> own_;
             std::uint64_t own_pos_ = 0;
+            std::unique_ptr<frame_stream> prod_;
+            std::uint64_t prod_pos_ = 0;
         public:
             auto skipped_files() const -> std::vector<std::string> { return own_ ? own_->skipped_files() : std::vector<std::string>{}; }
         };
@@ -286,7 +293,7 @@ namespace paris
         shared_frames(const std::string& proj_dir, bool enable_angles, const std::string& angle_file, std::uint16_t quality,
                       std::uint32_t dim_x, std::uint32_t dim_y, std::size_t capacity = 32)
         : dir_{proj_dir}, enable_angles_{enable_angles}, angle_file_{angle_file}, quality_{quality}, dim_x_{dim_x}, dim_y_{dim_y},
-          stream_{proj_dir, enable_angles, angle_file, quality}, ring_(capacity == 0 ? 1 : capacity)
+          ring_(capacity == 0 ? 1 : capacity)
         {}
 
         // frame_stream::next for the consumer behind `c`
@@ -297,59 +304,63 @@ namespace paris
             const auto k = c.next_++;
             if(c.own_) // once behind, stay on the private stream: it is already positioned
                 return from_own(c, k, dst, row_first, row_count);
+            const std::uint64_t ahead = ring_.size() / 2u; // how far beyond its own frame a waiting thread may produce
             std::shared_ptr<const entry> e;
             {
                 std::unique_lock<std::mutex> lock{m_};
                 for(;;)
                 {
-                    if(failed_ && k >= produced_)
-                        std::rethrow_exception(failed_); // the shared stream died at frame produced_: every consumer reports it
+                    if(failed_ && k >= fail_at_)
+                        std::rethrow_exception(failed_); // reading frame fail_at_ failed: every consumer that gets there reports it
                     if(ended_ && k >= end_)
                         return frame_info{};
-                    if(k < produced_)
+                    const auto& slot = ring_[k % ring_.size()];
+                    if(slot && slot->ordinal == k)
                     {
-                        const auto& slot = ring_[k % ring_.size()];
-                        if(slot && slot->ordinal == k)
-                        {
-                            e = slot;
-                            ++stats_.served;
-                        }
-                        break; // recycled: e stays empty
+                        e = slot;
+                        ++stats_.served;
+                        break;
                     }
-                    if(!producing_ && k == produced_)
+                    if(slot && slot->ordinal > k)
+                        break; // recycled: e stays empty
+                    // frame k is not there yet. Unclaimed frames are claimed in order; if k itself is already somebody's, this
+                    // thread reads the next unclaimed one (within `ahead`) rather than sleep
+                    if(claimed_ <= k || (claimed_ <= k + ahead && !(ended_ && claimed_ >= end_) && !(failed_ && claimed_ >= fail_at_)))
                     {
-                        producing_ = true;
+                        const auto j = claimed_++;
                         lock.unlock();
                         std::shared_ptr<const entry> fresh;
-                        try { fresh = produce(k); }
-                        catch(...)
-                        {
-                            // an I/O or allocation error while reading frame k (an angle file shorter than the frame set:
-                            // std::out_of_range; bad_alloc): the other consumers are parked in cv_.wait() for this frame and
-                            // must not wait for ever -- record the error, wake them (each rethrows it), rethrow here
-                            lock.lock();
-                            producing_ = false;
-                            failed_ = std::current_exception();
-                            cv_.notify_all();
-                            throw;
-                        }
+                        std::exception_ptr error;
+                        try { fresh = produce(c, j); }
+                        catch(...) { error = std::current_exception(); }
                         lock.lock();
-                        producing_ = false;
-                        if(fresh)
+                        if(error)
                         {
-                            ring_[k % ring_.size()] = fresh;
-                            ++produced_;
+                            // an I/O or allocation error while reading frame j (an angle file shorter than the frame set:
+                            // std::out_of_range; bad_alloc): consumers parked in cv_.wait() for it must not wait for ever
+                            if(!failed_ || j < fail_at_)
+                            {
+                                failed_ = error;
+                                fail_at_ = j;
+                            }
+                        }
+                        else if(fresh)
+                        {
+                            auto& target = ring_[j % ring_.size()];
+                            if(!target || target->ordinal < j) // (a straggler never replaces a later frame)
+                                target = fresh;
                             ++stats_.produced;
                         }
-                        else
+                        else if(!ended_ || j < end_)
                         {
-                            ended_ = true;
-                            end_ = k;
+                            ended_ = true; // the stream ends before frame j
+                            end_ = j;
+                            skipped_ = c.prod_->skipped_files(); // this stream has seen every file
                         }
                         cv_.notify_all();
                         continue;
                     }
-                    cv_.wait(lock); // another thread is reading frame produced_ (this one, or one before it)
+                    cv_.wait(lock); // frame k is being read by another thread and there is nothing left to help with
                 }
             }
             if(!e)
@@ -360,10 +371,11 @@ namespace paris
             return e->info;
         }
 
+        // the files the shared streams skipped (complete once a consumer has reached the end of the set)
         auto skipped_files() const -> std::vector<std::string>
         {
             std::lock_guard<std::mutex> lock{m_};
-            return stream_.skipped_files();
+            return skipped_;
         }
 
         auto stats() const -> counters
@@ -380,9 +392,18 @@ namespace paris
             std::vector<float> pixels; // the whole frame (consumers want different bands)
         };
 
-        // reads the next kept frame of the shared stream; only ever called by one thread at a time (producing_)
-        auto produce(std::uint64_t k) -> std::shared_ptr<const entry>
+        // reads kept frame j through the cursor's producing stream (frames are claimed in rising order, so the stream only ever
+        // moves forward); nullptr when the set ends before frame j. Runs without the lock, several threads at a time.
+        auto produce(cursor& c, std::uint64_t j) -> std::shared_ptr<const entry>
         {
+            if(!c.prod_)
+            {
+                c.prod_.reset(new frame_stream{dir_, enable_angles_, angle_file_, quality_});
+                c.prod_pos_ = 0;
+            }
+            for(; c.prod_pos_ < j; ++c.prod_pos_) // frames other threads produce are stepped over without conversion
+                if(!c.prod_->next(nullptr, dim_x_, dim_y_, 0, 0).valid())
+                    return nullptr;
             // frame buffers are recycled: the deleter of an entry hands its pixel vector back (a fresh 16 MiB vector per
             // frame would cost a page-faulting zero fill each time)
             auto* raw = new entry;
@@ -402,9 +423,10 @@ namespace paris
                 }
                 delete d;
             }};
-            e->ordinal = k;
+            e->ordinal = j;
             e->pixels.resize(static_cast<std::size_t>(dim_x_) * dim_y_);
-            e->info = stream_.next(e->pixels.data(), dim_x_, dim_y_, 0, dim_y_);
+            e->info = c.prod_->next(e->pixels.data(), dim_x_, dim_y_, 0, dim_y_);
+            ++c.prod_pos_;
             if(!e->info.valid())
                 return nullptr;
             return e;
@@ -437,13 +459,14 @@ namespace paris
         std::uint32_t dim_x_, dim_y_;
         mutable std::mutex m_;
         std::condition_variable cv_;
-        frame_stream stream_;
         std::mutex spare_m_;
         std::vector<std::vector<float>> spare_; // declared before ring_: the entries' deleters use it while ring_ is destroyed
         std::vector<std::shared_ptr<const entry>> ring_;
-        std::uint64_t produced_ = 0, end_ = 0;
-        bool producing_ = false, ended_ = false;
-        std::exception_ptr failed_; // set once, under m_, when produce() threw
+        std::uint64_t claimed_ = 0;             // frames 0 .. claimed_ - 1 have a producer (or are done)
+        std::uint64_t end_ = 0, fail_at_ = 0;
+        bool ended_ = false;
+        std::exception_ptr failed_; // set under m_ when a produce() threw, with the frame it was reading
+        std::vector<std::string> skipped_;
         counters stats_;
     };
 }

@@ -94,7 +94,7 @@ def test_one_thread_per_device_fan_out(tmp_path, oracle):
     geo = write_dataset(oracle, tmp_path / "in")
     env = dict(os.environ, PARIS_HIP_VIRTUAL_DEVICES="3")
     r = subprocess.run([EXE, "--geometry", geo, "--input", str(tmp_path / "in"), "--output", str(tmp_path / "out"), "--name", "kat",
-                        "--slabs", "7"], capture_output=True, text=True, timeout=300, env=env)
+                        "--slabs", "7", "--share-frames", "1"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("device ")]
     assert len(lines) == 3 and sum(int(l.split(":")[1].split()[0]) for l in lines) == 7  # 7 tasks over 3 threads
@@ -108,6 +108,17 @@ def test_one_thread_per_device_fan_out(tmp_path, oracle):
     head, vol = F.ddbvf_read(str(tmp_path / "out" / "kat.ddbvf"))
     assert head == F.ddbvf_header_bytes(67, 67, 61)
     assert_close(vol, oracle_volume(oracle, range(8)))
+    # a stream per device thread instead (what the driver picks by itself when the slabs of a pass need little more than one
+    # detector's worth of rows between them): same volume; left to itself the driver reports which of the two it took
+    for extra in (["--share-frames", "0"], []):
+        r = subprocess.run([EXE, "--geometry", geo, "--input", str(tmp_path / "in"), "--output", str(tmp_path / "out1"), "--name", "kat",
+                            "--slabs", "7"] + extra, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        own = [l for l in r.stdout.splitlines() if l.startswith("frame source: one stream per device thread")]
+        shared = [l for l in r.stdout.splitlines() if l.startswith("shared frame source:")]
+        assert len(own) + len(shared) == 1 and (len(own) == 1 or not extra)
+        _, vol = F.ddbvf_read(str(tmp_path / "out1" / "kat.ddbvf"))
+        assert_close(vol, oracle_volume(oracle, range(8)))
     # the memory-driven split sees three devices: at least one slab per device (src/cuda/subvolume_information.cpp:79)
     r = subprocess.run([EXE, "--geometry", geo, "--input", str(tmp_path / "in"), "--output", str(tmp_path / "out2")],
                        capture_output=True, text=True, timeout=300, env=env)

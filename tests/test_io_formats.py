@@ -80,6 +80,23 @@ def test_his_writer_round_trip(io, tmp_path):
             assert np.array_equal(got, a) and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.uint32, np.float64, np.float32])
+def test_tools_his_writer_is_read_back(io, tmp_path, dtype):
+    """tools/his_write.py (the data sets of tools/e2e_bench.py and tools/shared_source_bench.py are written with it, not with the
+    oracle): what it writes is what the host reader loads, and -- the unused file-size field aside -- the oracle's encoding."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from his_write import NUMBER_TYPE, write_his
+    fr = np.random.default_rng(3).integers(0, 250, size=(4, 6, 11)).astype(dtype)
+    path = tmp_path / "t.his"
+    write_his(str(path), fr, 24)
+    got = his_load(io, path)
+    assert len(got) == 4 and all(np.array_equal(g, f.astype(np.float32)) for g, f in zip(got, fr))
+    a, b = bytearray(path.read_bytes()), bytearray(F.his_file_bytes(fr, NUMBER_TYPE[np.dtype(dtype)], 24))
+    a[6:10] = b[6:10] = b"\0\0\0\0"
+    assert a == b
+
+
 def test_ddbvf_layout_and_slab_offsets(io, tmp_path):
     dx, dy, dz = 5, 3, 7
     vol = np.arange(dx * dy * dz, dtype=np.float32).reshape(dz, dy, dx)
@@ -223,11 +240,15 @@ def test_his_reader_random_files(io, tmp_path, seed):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-@pytest.mark.parametrize("capacity,delays,expect_reread", [(32, (0, 0, 0), False), (2, (0, 0, 3000), True)])
+@pytest.mark.parametrize("capacity,delays,expect_reread", [(32, (0, 0, 0), False), (2, (0, 0, 3000), True),
+                                                           (4, (0, 300, 0, 900, 0, 0, 100, 0), None), (1, (0, 0, 0, 0), None),
+                                                           (32, (0,) * 8, False)])
 def test_shared_frames_read_each_frame_once(io, tmp_path, capacity, delays, expect_reread):
-    """shared_frames (the read-once source of the multi-device driver): three consumers, each with its
+    """shared_frames (the read-once source of the multi-device driver): the consumers, each with its
     own detector row band, get exactly frame_stream's frames, indices and angles; every frame is converted from the files
-    once; a consumer that lags further than the ring is deep falls back to its own stream and still gets the same data."""
+    at most once by the shared streams (several frames are in production at a time, one thread each); a consumer that lags
+    further than the ring is deep falls back to its own stream and still gets the same data. Eight consumers on a ring of
+    four (and four on a ring of one) stress the claim order, stragglers and recycling; there only the data is checked."""
     io.paris_io_shared_scan.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p,
                                         _u32p, C.c_uint32, C.c_uint32, _u32p, _u32p, _fp, _fp, C.POINTER(C.c_uint64)]
     rng = np.random.default_rng(7)
@@ -242,9 +263,10 @@ def test_shared_frames_read_each_frame_once(io, tmp_path, capacity, delays, expe
     (d / "b_broken.his").write_bytes(b"\x01" * 90)  # skipped by every stream
     ang = tmp_path / "ang.txt"
     ang.write_text(" ".join(str(2.5 * i) for i in range(len(frames))))
-    bands = [(0, h), (3, 4), (10, 2)]
+    nt = len(delays)
+    bands = [[(0, h), (3, 4), (10, 2), (5, 7)][t % 4] for t in range(nt)]
     for quality in (1, 2):
-        cap, nt = 16, 3
+        cap = 16
         n = (C.c_uint32 * nt)()
         idx = (C.c_uint32 * (nt * cap))()
         phi = (C.c_float * (nt * cap))()
@@ -263,9 +285,11 @@ def test_shared_frames_read_each_frame_once(io, tmp_path, capacity, delays, expe
                 assert np.array_equal(data[t, j, first:first + count], frames[i][first:first + count])
                 assert np.all(data[t, j, :first] == -7.0) and np.all(data[t, j, first + count:] == -7.0)
         produced, served, reread = counters[0], counters[1], counters[2]
-        assert produced == len(keep)                       # every kept frame converted from the files exactly once
+        assert produced <= len(keep)                       # no kept frame converted by the shared streams twice
         assert served + reread == nt * len(keep)           # every request answered
-        assert (reread > 0) == expect_reread
+        if expect_reread is not None:
+            assert produced == len(keep)                   # consumers in step: every frame went through the ring
+            assert (reread > 0) == expect_reread
 
 
 @pytest.mark.timeout(120)

@@ -12,22 +12,21 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
-from oracle import formats as F  # noqa: E402  (tool, not product: only builds test input)
+from his_write import write_his  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n_proj = int(sys.argv[2]) if len(sys.argv) > 2 else 720
 per_file = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 work = sys.argv[4] if len(sys.argv) > 4 else "/tmp/paris_e2e"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-exe = os.path.join(root, "paris_amd", "host", "demo", "paris.hip")
+exe = os.environ.get("PARIS_E2E_EXE") or os.path.join(root, "paris_amd", "host", "demo", "paris.hip")  # another build for an A/B
 
 os.makedirs(os.path.join(work, "in"), exist_ok=True)
 rng = np.random.default_rng(0)
 t0 = time.time()
 for k in range(0, n_proj, per_file):
     fr = rng.integers(0, 60000, size=(min(per_file, n_proj - k), n, n), dtype=np.uint16)
-    with open(os.path.join(work, "in", "scan_%04d.his" % (k // per_file)), "wb") as f:
-        f.write(F.his_file_bytes(fr, 4, 32))
+    write_his(os.path.join(work, "in", "scan_%04d.his" % (k // per_file)), fr, 32)
 print("wrote %d frames of %dx%d u16 in %.1f s" % (n_proj, n, n, time.time() - t0), flush=True)
 with open(os.path.join(work, "geo.ini"), "w") as f:
     f.write("n_row=%d\nn_col=%d\nl_px_row=0.2\nl_px_col=0.2\ndelta_s=0\ndelta_t=0\nd_so=500\nd_od=500\ndelta_phi=%r\n" % (n, n, 360.0 / n_proj))
