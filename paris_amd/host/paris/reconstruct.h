@@ -11,7 +11,8 @@
 //     stream fence, the host fills the other group meanwhile;
 //   - per slab only the detector rows it can read are converted, uploaded, weighted and filtered (8f-4,
 //     paris_hip_slab_row_band); the slab reaches the file through two pinned chunks (D2H of one overlapping the write
-//     of the other) instead of a pinned copy of the whole slab;
+//     of the other) instead of a pinned copy of the whole slab, on a drain thread with a ctx of its own: a device that has
+//     another slab to do works on it in a second volume buffer while the finished one is copied down and written;
 //   - geometry constants are derived per call and the slab offset is passed per task (Q1, Q2), the source restarts
 //     its frame index per task (Q5), slabs are written at their own slice offset (Q4);
 //   - slab planning is 64-bit and memory driven (paris_hip_make_subvolume_information) with an optional fixed count.
@@ -19,14 +20,18 @@
 #define PARIS_AMD_HOST_RECONSTRUCT_H_
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <deque>
+#include <exception>
 #include <future>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <queue>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -61,6 +66,10 @@ namespace paris
         // the files through a stream of its own (only its slab's detector rows when row_band is on), -1 = decided by how many
         // detector rows the slabs of a pass need between them (run())
         int share_frames = -1;
+        bool two_volumes = true; // a device with several slabs to do keeps two volume buffers when memory allows (drain thread, below)
+        // memory-driven split that gives every device one slab of at least 1 GiB: cut each into this many (0: leave it), so that all
+        // but the last of a device's slabs go to the file while the next one is reconstructed
+        int pipeline_slabs = 4;
     };
 
     // src/task.h:33-57
@@ -171,6 +180,8 @@ namespace paris
         std::uint32_t tasks = 0, projections = 0;
         std::uint64_t band_rows = 0; // sum over tasks of the detector rows processed per projection (f4)
         double source_s = 0, enqueue_s = 0, drain_s = 0, save_s = 0;
+        double drain_wait_s = 0; // the device thread waiting for the drain thread (a volume buffer to come free; the end of the run)
+        bool two_volumes = false; // a second slab buffer was in use: slab k went to the file while slab k + 1 was reconstructed
         std::vector<std::string> skipped;
     };
 
@@ -236,6 +247,172 @@ namespace paris
         }
     }
 
+    namespace detail
+    {
+        // A finished slab's way to the file (src/sink.cpp:72-82), on a thread and a ctx of its own: waits for the fence the device
+        // thread recorded behind the slab's last kernel, copies the slab down in chunks of whole slices through two pinned buffers
+        // (D2H of chunk k + 1 on the drain ctx's stream overlaps the file write of chunk k) and writes them at the slab's slice
+        // offset. The device thread meanwhile reconstructs its next slab in another volume buffer; it only waits when it wants a
+        // buffer back (wait) or is done (finish). An error in here is rethrown in the device thread by the next wait / finish.
+        class volume_drain
+        {
+        public:
+            struct job
+            {
+                const float* d_v = nullptr;
+                std::uint32_t dim_x = 0, dim_y = 0, dim_z = 0, first = 0; // `first`: global slice of the slab's slice 0
+                paris_hip_fence* ready = nullptr;                          // recorded by the device thread on its own ctx
+                int buffer = 0;                                            // which of the device thread's volume buffers d_v is
+            };
+
+            volume_drain(int device, sink& out, std::size_t chunk_bytes) : device_{device}, out_(out), chunk_bytes_{chunk_bytes}
+            {
+                thread_ = std::thread{[this] { work(); }};
+            }
+            volume_drain(const volume_drain&) = delete;
+            auto operator=(const volume_drain&) -> volume_drain& = delete;
+            ~volume_drain()
+            {
+                {
+                    std::lock_guard<std::mutex> lock{m_};
+                    quit_ = true;
+                }
+                cv_.notify_all();
+                if(thread_.joinable())
+                    thread_.join();
+            }
+
+            void submit(const job& j)
+            {
+                {
+                    std::lock_guard<std::mutex> lock{m_};
+                    if(error_)
+                        std::rethrow_exception(error_);
+                    jobs_.push_back(j);
+                    ++busy_[j.buffer & 1];
+                }
+                cv_.notify_all();
+            }
+            // until no submitted slab lives in volume buffer `buffer` any more
+            void wait(int buffer)
+            {
+                std::unique_lock<std::mutex> lock{m_};
+                cv_.wait(lock, [&] { return error_ || busy_[buffer & 1] == 0; });
+                if(error_)
+                    std::rethrow_exception(error_);
+            }
+            void finish()
+            {
+                wait(0);
+                wait(1);
+            }
+            auto drain_seconds() -> double { std::lock_guard<std::mutex> lock{m_}; return drain_s_; }
+            auto save_seconds() -> double { std::lock_guard<std::mutex> lock{m_}; return save_s_; }
+
+        private:
+            void work()
+            {
+                paris_hip_ctx* ctx = nullptr;
+                float* h_stage[2] = {nullptr, nullptr};
+                paris_hip_fence* stage_fence[2] = {nullptr, nullptr};
+                std::size_t stage_floats = 0;
+                try
+                {
+                    rt(paris_hip_ctx_create(device_, nullptr, PARIS_HIP_CTX_DEFAULT, &ctx), "set_device()");
+                    for(;;)
+                    {
+                        job j;
+                        {
+                            std::unique_lock<std::mutex> lock{m_};
+                            cv_.wait(lock, [&] { return quit_ || !jobs_.empty(); });
+                            if(jobs_.empty())
+                                break;
+                            j = jobs_.front();
+                            jobs_.pop_front();
+                        }
+                        double drain_s = 0, save_s = 0;
+                        auto t0 = clock::now();
+                        rt(paris_hip_fence_wait(ctx, j.ready), "fence wait"); // the slab's last kernel has run
+                        // the host side of the slab is two pinned chunks of whole slices (the reference allocates the whole slab:
+                        // src/sink.cpp:76); pinning gigabytes costs more than the reconstruction of a small data set
+                        const auto slice_floats = static_cast<std::size_t>(j.dim_x) * j.dim_y;
+                        const auto voxels = slice_floats * j.dim_z;
+                        const auto want_floats = std::max(slice_floats, std::min(voxels, chunk_bytes_ / sizeof(float)) / slice_floats * slice_floats);
+                        if(want_floats > stage_floats)
+                        {
+                            for(int s = 0; s < 2; ++s)
+                            {
+                                rt(paris_hip_free_host(ctx, h_stage[s]), "free");
+                                h_stage[s] = nullptr;
+                                void* p = nullptr;
+                                rt(paris_hip_malloc_host(ctx, want_floats * sizeof(float), &p), "make_volume_host()");
+                                h_stage[s] = static_cast<float*>(p);
+                                if(stage_fence[s] == nullptr)
+                                    rt(paris_hip_fence_create(ctx, &stage_fence[s]), "fence");
+                            }
+                            stage_floats = want_floats;
+                        }
+                        const auto chunk_z = static_cast<std::uint32_t>(stage_floats / slice_floats);
+                        const auto n_chunks = (j.dim_z + chunk_z - 1u) / chunk_z;
+                        const auto copy_down = [&](std::uint32_t c) {
+                            const auto z0 = c * chunk_z;
+                            const auto nz = std::min(chunk_z, j.dim_z - z0);
+                            rt(paris_hip_memcpy_volume_d2h(ctx, h_stage[c % 2u], j.d_v + static_cast<std::size_t>(z0) * slice_floats, j.dim_x, j.dim_y, nz),
+                               "copy_d2h()");
+                            rt(paris_hip_fence_record(ctx, stage_fence[c % 2u]), "fence record");
+                        };
+                        copy_down(0);
+                        drain_s += since(t0);
+                        for(std::uint32_t c = 0; c < n_chunks; ++c)
+                        {
+                            t0 = clock::now();
+                            if(c + 1u < n_chunks)
+                                copy_down(c + 1u); // its buffer was written to the file in the previous iteration
+                            rt(paris_hip_fence_wait(ctx, stage_fence[c % 2u]), "fence wait");
+                            drain_s += since(t0);
+                            t0 = clock::now();
+                            const auto z0 = c * chunk_z;
+                            out_.save(h_stage[c % 2u], j.dim_x, j.dim_y, std::min(chunk_z, j.dim_z - z0), j.first + z0); // :107
+                            save_s += since(t0);
+                        }
+                        {
+                            std::lock_guard<std::mutex> lock{m_};
+                            --busy_[j.buffer & 1];
+                            drain_s_ += drain_s;
+                            save_s_ += save_s;
+                        }
+                        cv_.notify_all();
+                    }
+                }
+                catch(...)
+                {
+                    std::lock_guard<std::mutex> lock{m_};
+                    error_ = std::current_exception();
+                    jobs_.clear();
+                    cv_.notify_all();
+                }
+                for(int s = 0; s < 2; ++s)
+                {
+                    paris_hip_fence_destroy(ctx, stage_fence[s]);
+                    paris_hip_free_host(ctx, h_stage[s]);
+                }
+                paris_hip_ctx_destroy(ctx);
+            }
+
+            int device_;
+            sink& out_;
+            std::size_t chunk_bytes_;
+            std::mutex m_;
+            std::condition_variable cv_;
+            std::deque<job> jobs_;
+            int busy_[2] = {0, 0};
+            bool quit_ = false;
+            std::exception_ptr error_;
+            double drain_s_ = 0, save_s_ = 0;
+            std::thread thread_; // last: started when everything above exists
+        };
+    }
+
     // src/main.cpp:79-109, pipelined
     inline auto reconstruct(task_queue& queue, int device, sink& out, const program_options& po, frame_pool* pool = nullptr) -> device_report
     {
@@ -260,22 +437,25 @@ namespace paris
         float* d_all = nullptr; // the device frames of all slots, one under the other: slot s starts at row s * n_col
         std::size_t d_pitch = 0, h16_pitch = 0, h16_stride = 0;
         std::uint16_t* d_half = nullptr;
-        float* d_v = nullptr;
-        float* h_stage[2] = {nullptr, nullptr}; // pinned staging for the drain: D2H of chunk k+1 overlaps the file write of chunk k
-        paris_hip_fence* stage_fence[2] = {nullptr, nullptr};
-        std::size_t stage_floats = 0;
+        // Two volume buffers when the device has room for them: the slab just finished is copied down and written by the drain
+        // thread while the next one is reconstructed in the other buffer. The second buffer is allocated when (and if) this device
+        // thread pops a second task and a slab's worth of memory is still free.
+        float* d_vol[2] = {nullptr, nullptr};
+        std::size_t v_cap[2] = {0, 0};
+        paris_hip_fence* slab_done[2] = {nullptr, nullptr};
+        std::unique_ptr<volume_drain> drain;
         auto cleanup = [&] {
+            drain.reset(); // joins the drain thread: nothing reads the volumes or the fences after this
             for(auto f : fence)
                 paris_hip_fence_destroy(ctx, f);
             for(int s = 0; s < slots; ++s)
                 paris_hip_free_host(ctx, h_buf[s]);
             paris_hip_free(ctx, d_all);
             paris_hip_free(ctx, d_half);
-            paris_hip_free(ctx, d_v);
             for(int s = 0; s < 2; ++s)
             {
-                paris_hip_fence_destroy(ctx, stage_fence[s]);
-                paris_hip_free_host(ctx, h_stage[s]);
+                paris_hip_free(ctx, d_vol[s]);
+                paris_hip_fence_destroy(ctx, slab_done[s]);
             }
             paris_hip_ctx_destroy(ctx);
         };
@@ -307,41 +487,42 @@ namespace paris
                 h16_stride = h16_pitch * n_col;
             }
 
+            for(auto& f : slab_done)
+                rt(paris_hip_fence_create(ctx, &f), "fence");
+            drain.reset(new volume_drain{device, out, po.drain_chunk_bytes});
             task t{};
-            std::size_t v_cap = 0;
+            bool two = false, decided = false;
             while(queue.pop(t)) // :89-91
             {
                 const bool last = (t.num - t.id) <= 1;                                    // :92
                 const auto dim_z = t.subvol_geo.dim_z + (last ? t.subvol_geo.remainder : 0u); // make_volume: src/make_volume.cpp:32-34
                 const auto offset = t.id * t.subvol_geo.dim_z;                             // :96
                 const auto voxels = static_cast<std::size_t>(t.subvol_geo.dim_x) * t.subvol_geo.dim_y * dim_z;
-                if(voxels > v_cap) // slabs of one run have (almost) the same size: allocate once, re-zero per task
+                if(rep.tasks == 1u && !decided) // a second slab for this device: is there room to keep the first while it is written?
+                {
+                    std::size_t free_b = 0, total_b = 0;
+                    rt(paris_hip_device_memory(device, &free_b, &total_b), "device memory");
+                    // a slab the size of the largest of the run (the last one carries the remainder) plus slack for the runtime
+                    const auto need = static_cast<std::size_t>(t.subvol_geo.dim_x) * t.subvol_geo.dim_y * (t.subvol_geo.dim_z + t.subvol_geo.remainder) * sizeof(float);
+                    two = po.two_volumes && free_b > need + need / 8u + (std::size_t{256} << 20);
+                    decided = true;
+                    rep.two_volumes = two;
+                }
+                const int b = two ? static_cast<int>(rep.tasks & 1u) : 0;
+                auto t0 = clock::now();
+                drain->wait(b); // the slab that lived in this buffer is in the file
+                rep.drain_wait_s += since(t0);
+                float*& d_v = d_vol[b];
+                if(voxels > v_cap[b]) // slabs of one run have (almost) the same size: allocate once, re-zero per task
                 {
                     rt(paris_hip_free(ctx, d_v), "free");
                     d_v = nullptr;
+                    v_cap[b] = 0;
                     rt(paris_hip_malloc_volume(ctx, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z, &d_v), "make_volume()");
-                    v_cap = voxels;
+                    v_cap[b] = voxels;
                 }
                 else
                     rt(paris_hip_memset_volume(ctx, d_v, t.subvol_geo.dim_x, t.subvol_geo.dim_y, dim_z), "make_volume()");
-                // the host side of the slab is two pinned chunks of whole slices (the reference allocates the whole slab:
-                // src/sink.cpp:76); pinning gigabytes costs more than the reconstruction of a small data set
-                const auto slice_floats = static_cast<std::size_t>(t.subvol_geo.dim_x) * t.subvol_geo.dim_y;
-                const auto want_floats = std::max(slice_floats, std::min(voxels, po.drain_chunk_bytes / sizeof(float)) / slice_floats * slice_floats);
-                if(want_floats > stage_floats)
-                {
-                    for(int s = 0; s < 2; ++s)
-                    {
-                        rt(paris_hip_free_host(ctx, h_stage[s]), "free");
-                        h_stage[s] = nullptr;
-                        void* p = nullptr;
-                        rt(paris_hip_malloc_host(ctx, want_floats * sizeof(float), &p), "make_volume_host()");
-                        h_stage[s] = static_cast<float*>(p);
-                        if(stage_fence[s] == nullptr)
-                            rt(paris_hip_fence_create(ctx, &stage_fence[s]), "fence");
-                    }
-                    stage_floats = want_floats;
-                }
 
                 std::uint32_t band_first = 0, band_count = n_col;
                 if(po.row_band)
@@ -350,7 +531,7 @@ namespace paris
                 rep.band_rows += band_count;
                 const auto row_bytes = static_cast<std::size_t>(n_row) * sizeof(float);
 
-                auto t0 = clock::now();
+                t0 = clock::now();
                 // :93 (index restarts per task). Several devices: the frames come from the pass's read-once source
                 auto shared = pool != nullptr ? pool->get(t) : std::shared_ptr<shared_frames>{};
                 auto cur = shared_frames::cursor{};
@@ -429,33 +610,24 @@ namespace paris
                 for(const auto& s : (shared ? cur.skipped_files() : own->skipped_files())) // the shared source's list: run_report
                     rep.skipped.push_back(s);
 
-                // src/sink.cpp:76-82 in chunks of whole slices: copy chunk k+1 down while chunk k goes to the file
-                const auto chunk_z = static_cast<std::uint32_t>(stage_floats / slice_floats);
-                const auto n_chunks = (dim_z + chunk_z - 1u) / chunk_z;
-                const auto copy_down = [&](std::uint32_t c) {
-                    const auto z0 = c * chunk_z;
-                    const auto nz = std::min(chunk_z, dim_z - z0);
-                    rt(paris_hip_memcpy_volume_d2h(ctx, h_stage[c % 2u], d_v + static_cast<std::size_t>(z0) * slice_floats, t.subvol_geo.dim_x,
-                                                   t.subvol_geo.dim_y, nz), "copy_d2h()");
-                    rt(paris_hip_fence_record(ctx, stage_fence[c % 2u]), "fence record");
-                };
-                t0 = clock::now();
-                copy_down(0);
-                rep.drain_s += since(t0);
-                for(std::uint32_t c = 0; c < n_chunks; ++c)
-                {
-                    t0 = clock::now();
-                    if(c + 1u < n_chunks)
-                        copy_down(c + 1u); // its buffer was written to the file in the previous iteration
-                    rt(paris_hip_fence_wait(ctx, stage_fence[c % 2u]), "fence wait");
-                    rep.drain_s += since(t0);
-                    t0 = clock::now();
-                    const auto z0 = c * chunk_z;
-                    out.save(h_stage[c % 2u], t.subvol_geo.dim_x, t.subvol_geo.dim_y, std::min(chunk_z, dim_z - z0), offset + z0); // :107
-                    rep.save_s += since(t0);
-                }
+                // src/sink.cpp:76-82: the slab is complete behind this fence; the drain thread takes it from there
+                rt(paris_hip_fence_record(ctx, slab_done[b]), "fence record");
+                auto j = volume_drain::job{};
+                j.d_v = d_v;
+                j.dim_x = t.subvol_geo.dim_x;
+                j.dim_y = t.subvol_geo.dim_y;
+                j.dim_z = dim_z;
+                j.first = offset;
+                j.ready = slab_done[b];
+                j.buffer = b;
+                drain->submit(j);
                 ++rep.tasks;
             }
+            const auto t_end = clock::now();
+            drain->finish();
+            rep.drain_wait_s += since(t_end);
+            rep.drain_s = drain->drain_seconds();
+            rep.save_s = drain->save_seconds();
         }
         catch(...)
         {
@@ -507,8 +679,23 @@ namespace paris
             r.info.geo = {r.roi_geo.dim_x, r.roi_geo.dim_y, r.roi_geo.dim_z / num, r.roi_geo.dim_z % num};
         }
         else // :137, with the driver's own per-device buffers charged next to the slab
+        {
             detail::rt(paris_hip_make_subvolume_information_reserving(&r.roi_geo, &po.det_geo, n_dev, detail::driver_bytes(po), &r.info),
                        "make_subvolume_information()");
+            // The volume fits (one slab per device): nothing of it could reach the file before the last projection is in. Thinner
+            // slabs, several per device, let the drain thread write slab k while slab k + 1 is reconstructed (two volume buffers:
+            // they fit where the one big slab did); each slab only reads its own detector rows, so the extra passes over the
+            // projections cost little (row band, f4).
+            const auto per = static_cast<std::uint32_t>(po.pipeline_slabs > 0 ? po.pipeline_slabs : 0);
+            const auto slab_bytes = static_cast<std::uint64_t>(r.info.geo.dim_x) * r.info.geo.dim_y * r.info.geo.dim_z * sizeof(float);
+            if(po.two_volumes && po.row_band && per > 1u && r.info.num == n_dev && slab_bytes >= (std::uint64_t{1} << 30)
+               && r.info.geo.dim_z >= 32u * per)
+            {
+                const auto num = static_cast<std::uint32_t>(n_dev) * per;
+                r.info.num = static_cast<int>(num);
+                r.info.geo = {r.roi_geo.dim_x, r.roi_geo.dim_y, r.roi_geo.dim_z / num, r.roi_geo.dim_z % num};
+            }
+        }
 
         task_queue queue{make_tasks(po, r.vol_geo, r.info)}; // :140-141
         sink out{po.output_path, po.prefix, r.roi_geo};           // :154
