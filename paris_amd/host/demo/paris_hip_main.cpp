@@ -4,7 +4,7 @@
 //
 //   paris.hip --geometry geo.ini --input <dir> --output <dir> [--name vol] [--angles file] [--quality q]
 //             [--roi --roi-x1 a --roi-x2 b --roi-y1 c --roi-y2 d --roi-z1 e --roi-z2 f]
-//             [--slabs n] [--devices n] [--f16] [--no-row-band] [--batch n] [--drain-chunk-kib n] [--share-frames 0|1] [--one-volume] [--pipeline-slabs n]
+//             [--slabs n] [--devices n] [--f16] [--no-row-band] [--batch n] [--drain-chunk-kib n] [--share-frames 0|1] [--one-volume] [--pipeline-slabs n] [--no-read-ahead]
 //             [--window ramp|shepp-logan]
 // geo.ini: key=value lines for n_row n_col l_px_row l_px_col delta_s delta_t d_so d_od delta_phi (:83-91).
 #include <cstdio>
@@ -77,7 +77,7 @@ int main(int argc, char** argv)
             {
                 std::printf("paris.hip --geometry geo.ini --input <dir of .his files> --output <dir> [--name vol] [--angles file] [--quality q]\n"
                             "          [--roi --roi-x1 a --roi-x2 b --roi-y1 c --roi-y2 d --roi-z1 e --roi-z2 f]\n"
-                            "          [--slabs n] [--devices n] [--f16] [--window ramp|shepp-logan] [--batch n] [--no-row-band] [--share-frames 0|1] [--one-volume] [--pipeline-slabs n]\n"
+                            "          [--slabs n] [--devices n] [--f16] [--window ramp|shepp-logan] [--batch n] [--no-row-band] [--share-frames 0|1] [--one-volume] [--pipeline-slabs n] [--no-read-ahead]\n"
                             "          [--drain-chunk-kib n]\n"
                             "geo.ini: key=value lines for n_row n_col l_px_row l_px_col delta_s delta_t d_so d_od delta_phi\n"
                             "Reconstructs the HIS projections of <dir> (sorted by path) into <output>/<name>.ddbvf on all MI355X of the node.\n");
@@ -110,6 +110,7 @@ int main(int argc, char** argv)
             else if(k == "--batch") po.batch = std::stoi(val());
             else if(k == "--share-frames") po.share_frames = std::stoi(val());
             else if(k == "--one-volume") po.two_volumes = false;
+            else if(k == "--no-read-ahead") po.read_ahead = false;
             else if(k == "--pipeline-slabs") po.pipeline_slabs = std::stoi(val());
             else if(k == "--drain-chunk-kib") po.drain_chunk_bytes = static_cast<std::size_t>(std::stoull(val())) << 10;
             else throw paris::stage_construction_error{"unknown option " + k};
@@ -138,10 +139,11 @@ int main(int argc, char** argv)
             std::printf("  skipped invalid file %s\n", s.c_str());
         for(const auto& d : r.devices)
         {
-            std::printf("device %d: %u task(s), %u projections, %.0f detector rows per projection; host: source %.3f s, enqueue %.3f s, "
+            std::printf("device %d: %u task(s), %u projections, %.0f detector rows per projection; host: setup %.3f s, source %.3f s%s, enqueue %.3f s, "
                         "waiting for the drain thread %.3f s (%s; drain thread: D2H %.3f s, save %.3f s)\n", d.device, d.tasks, d.projections,
-                        d.tasks ? static_cast<double>(d.band_rows) / d.tasks : 0.0, d.source_s, d.enqueue_s, d.drain_wait_s,
-                        d.two_volumes ? "two volume buffers" : "one volume buffer", d.drain_s, d.save_s);
+                        d.tasks ? static_cast<double>(d.band_rows) / d.tasks : 0.0, d.setup_s, d.source_s,
+                        po.read_ahead ? (" on the feed thread (the device thread waited " + std::to_string(d.source_wait_s).substr(0, 5) + " s for it)").c_str() : "",
+                        d.enqueue_s, d.drain_wait_s, d.two_volumes ? "two volume buffers" : "one volume buffer", d.drain_s, d.save_s);
             for(const auto& s : d.skipped)
                 std::printf("  skipped invalid file %s\n", s.c_str());
         }

@@ -25,6 +25,7 @@
 #include <cstring>
 #include <deque>
 #include <exception>
+#include <functional>
 #include <future>
 #include <map>
 #include <memory>
@@ -66,6 +67,7 @@ namespace paris
         // the files through a stream of its own (only its slab's detector rows when row_band is on), -1 = decided by how many
         // detector rows the slabs of a pass need between them (run())
         int share_frames = -1;
+        bool read_ahead = true;  // frames are read and converted by a feed thread per device, ahead of the device thread
         bool two_volumes = true; // a device with several slabs to do keeps two volume buffers when memory allows (drain thread, below)
         // memory-driven split that gives every device one slab of at least 1 GiB: cut each into this many (0: leave it), so that all
         // but the last of a device's slabs go to the file while the next one is reconstructed
@@ -180,6 +182,8 @@ namespace paris
         std::uint32_t tasks = 0, projections = 0;
         std::uint64_t band_rows = 0; // sum over tasks of the detector rows processed per projection (f4)
         double source_s = 0, enqueue_s = 0, drain_s = 0, save_s = 0;
+        double setup_s = 0;       // ctx, pinned slots, device frames: before the first task is popped
+        double source_wait_s = 0; // the device thread waiting for the feed thread's next frame (read_ahead)
         double drain_wait_s = 0; // the device thread waiting for the drain thread (a volume buffer to come free; the end of the run)
         bool two_volumes = false; // a second slab buffer was in use: slab k went to the file while slab k + 1 was reconstructed
         std::vector<std::string> skipped;
@@ -413,12 +417,123 @@ namespace paris
         };
     }
 
+    namespace detail
+    {
+        // The frames of one task, read and converted ahead of the device thread on a thread of their own, straight into the pinned
+        // upload slots (src/main.cpp:100 `load`, taken off the device thread: converting a frame costs about as much host time as
+        // enqueueing its upload, filter and share of a launch, and the two now overlap). The slots are filled in order, group after
+        // group; before it overwrites a group's slots the reader waits until the device thread has enqueued the launch that last used
+        // them (flushed) and for that launch's fence (paris_hip_fence_wait touches no ctx state: any thread may call it). The device
+        // thread takes the frames in the same order. An error while reading is rethrown by take().
+        class frame_feed
+        {
+        public:
+            frame_feed(paris_hip_ctx* ctx, std::function<frame_info(float*)> next, const std::vector<float*>& slots, std::uint32_t batch,
+                       const std::vector<paris_hip_fence*>& fences)
+            : ctx_{ctx}, next_{std::move(next)}, slots_(slots), batch_{batch}, fences_(fences)
+            {
+                thread_ = std::thread{[this] { work(); }};
+            }
+            frame_feed(const frame_feed&) = delete;
+            auto operator=(const frame_feed&) -> frame_feed& = delete;
+            ~frame_feed()
+            {
+                {
+                    std::lock_guard<std::mutex> lock{m_};
+                    quit_ = true;
+                }
+                cv_.notify_all();
+                if(thread_.joinable())
+                    thread_.join();
+            }
+
+            // the next frame's metadata; its pixels are in slot (taken so far) % slots. !valid(): the set is exhausted
+            auto take() -> frame_info
+            {
+                std::unique_lock<std::mutex> lock{m_};
+                cv_.wait(lock, [&] { return error_ || !ready_.empty(); });
+                if(ready_.empty())
+                    std::rethrow_exception(error_);
+                const auto info = ready_.front();
+                ready_.pop_front();
+                return info;
+            }
+            // the device thread has enqueued (and fenced) the launch over one more group of slots
+            void flushed()
+            {
+                {
+                    std::lock_guard<std::mutex> lock{m_};
+                    ++flushed_;
+                }
+                cv_.notify_all();
+            }
+            auto read_seconds() -> double { std::lock_guard<std::mutex> lock{m_}; return read_s_; }
+
+        private:
+            void work()
+            {
+                try
+                {
+                    const auto groups = static_cast<std::uint64_t>(fences_.size());
+                    for(std::uint64_t round = 0;; ++round)
+                    {
+                        {
+                            std::unique_lock<std::mutex> lock{m_};
+                            cv_.wait(lock, [&] { return quit_ || round < groups || flushed_ + groups > round; });
+                            if(quit_)
+                                return;
+                        }
+                        const auto g = static_cast<std::size_t>(round % groups);
+                        rt(paris_hip_fence_wait(ctx_, fences_[g]), "fence wait"); // whatever last used this group's slots is done
+                        for(std::uint32_t i = 0; i < batch_; ++i)
+                        {
+                            const auto t0 = clock::now();
+                            const auto info = next_(slots_[g * batch_ + i]);
+                            const auto dt = since(t0);
+                            {
+                                std::lock_guard<std::mutex> lock{m_};
+                                read_s_ += dt;
+                                ready_.push_back(info);
+                                if(quit_)
+                                    return;
+                            }
+                            cv_.notify_all();
+                            if(!info.valid())
+                                return;
+                        }
+                    }
+                }
+                catch(...)
+                {
+                    std::lock_guard<std::mutex> lock{m_};
+                    error_ = std::current_exception();
+                    cv_.notify_all();
+                }
+            }
+
+            paris_hip_ctx* ctx_;
+            std::function<frame_info(float*)> next_;
+            std::vector<float*> slots_;
+            std::uint32_t batch_;
+            std::vector<paris_hip_fence*> fences_;
+            std::mutex m_;
+            std::condition_variable cv_;
+            std::deque<frame_info> ready_;
+            std::uint64_t flushed_ = 0;
+            bool quit_ = false;
+            std::exception_ptr error_;
+            double read_s_ = 0;
+            std::thread thread_; // last: started when everything above exists
+        };
+    }
+
     // src/main.cpp:79-109, pipelined
     inline auto reconstruct(task_queue& queue, int device, sink& out, const program_options& po, frame_pool* pool = nullptr) -> device_report
     {
         using namespace detail;
         auto rep = device_report{};
         rep.device = device;
+        const auto t_setup = clock::now();
         paris_hip_ctx* ctx = nullptr;
         rt(paris_hip_ctx_create(device, nullptr, PARIS_HIP_CTX_DEFAULT, &ctx), "set_device()"); // :87
 
@@ -490,6 +605,7 @@ namespace paris
             for(auto& f : slab_done)
                 rt(paris_hip_fence_create(ctx, &f), "fence");
             drain.reset(new volume_drain{device, out, po.drain_chunk_bytes});
+            rep.setup_s = since(t_setup);
             task t{};
             bool two = false, decided = false;
             while(queue.pop(t)) // :89-91
@@ -540,6 +656,7 @@ namespace paris
                     own.reset(new frame_stream{t.input_path, t.enable_angles, t.angle_path, t.quality});
                 rep.source_s += since(t0);
                 std::uint32_t group = 0, filled = 0; // frames of the current group already enqueued
+                auto feed = std::unique_ptr<frame_feed>{};
                 auto sines = std::vector<float>(batch), cosines = std::vector<float>(batch);
                 const float delta_s = t.det_geo.delta_s * t.det_geo.l_px_row, delta_t = t.det_geo.delta_t * t.det_geo.l_px_col; // src/backprojection.cpp:49-50
                 // frames of up to 1024 x 1024 are weighted and filtered group by group (one launch for up to `batch` frames when the
@@ -567,20 +684,37 @@ namespace paris
                     rep.enqueue_s += since(t1);
                     group = (group + 1u) % groups;
                     filled = 0;
+                    if(feed)
+                        feed->flushed();
                 };
+                // f4: only the detector rows this slab can read are converted, uploaded, weighted and filtered; the
+                // buffers keep their full size, rows outside the band are never read for a voxel of the slab
+                const auto next_frame = [&](float* dst) {
+                    return shared ? shared->next(cur, dst, n_row, n_col, band_first, band_count)
+                                  : own->next(dst, n_row, n_col, band_first, band_count); // :100, straight into pinned memory
+                };
+                if(po.read_ahead)
+                    feed.reset(new frame_feed{ctx, next_frame, h_buf, batch, fence});
                 for(;;) // :98
                 {
                     const int slot = static_cast<int>(group * batch + filled);
-                    t0 = clock::now();
-                    if(filled == 0)
-                        rt(paris_hip_fence_wait(ctx, fence[group]), "fence wait"); // everything that last used this group's slots is done
-                    rep.enqueue_s += since(t0);
-                    // f4: only the detector rows this slab can read are converted, uploaded, weighted and filtered; the
-                    // buffers keep their full size, rows outside the band are never read for a voxel of the slab
-                    t0 = clock::now();
-                    const auto p = shared ? shared->next(cur, h_buf[slot], n_row, n_col, band_first, band_count)
-                                          : own->next(h_buf[slot], n_row, n_col, band_first, band_count); // :100, straight into pinned memory
-                    rep.source_s += since(t0);
+                    auto p = frame_info{};
+                    if(feed)
+                    {
+                        t0 = clock::now();
+                        p = feed->take(); // read by the feed thread, which also waited for the slot to be free
+                        rep.source_wait_s += since(t0);
+                    }
+                    else
+                    {
+                        t0 = clock::now();
+                        if(filled == 0)
+                            rt(paris_hip_fence_wait(ctx, fence[group]), "fence wait"); // everything that last used this group's slots is done
+                        rep.enqueue_s += since(t0);
+                        t0 = clock::now();
+                        p = next_frame(h_buf[slot]);
+                        rep.source_s += since(t0);
+                    }
                     if(!p.valid())
                         break;
                     if(p.dim_x != n_row || p.dim_y != n_col)
@@ -607,6 +741,11 @@ namespace paris
                     ++rep.projections;
                 }
                 flush(); // the last, possibly partial group
+                if(feed)
+                {
+                    rep.source_s += feed->read_seconds();
+                    feed.reset(); // joins the feed thread: the source objects are this thread's again
+                }
                 for(const auto& s : (shared ? cur.skipped_files() : own->skipped_files())) // the shared source's list: run_report
                     rep.skipped.push_back(s);
 

@@ -71,14 +71,20 @@ def test_his_to_ddbvf(tmp_path, oracle, slabs):
 
 
 @pytest.mark.parametrize("extra", [["--drain-chunk-kib", 40], ["--drain-chunk-kib", 1, "--slabs", 2], ["--no-row-band", "--slabs", 4],
-                                   ["--batch", 1], ["--batch", 3, "--slabs", 2], ["--batch", 32], ["--batch", 64], ["--f16"]])
+                                   ["--batch", 1], ["--batch", 3, "--slabs", 2], ["--batch", 32], ["--batch", 64], ["--f16"],
+                                   ["--slabs", 5], ["--slabs", 5, "--one-volume"], ["--slabs", 2, "--drain-chunk-kib", 1],
+                                   ["--no-read-ahead"], ["--no-read-ahead", "--batch", 3, "--slabs", 3], ["--batch", 2, "--slabs", 3]])
 def test_chunked_drain_and_row_band_switch(tmp_path, oracle, extra):
     """The volume goes to the file through two pinned chunks of whole slices (67 x 67 floats = 17.5 KiB per slice: 40 KiB =
     2 slices per chunk, 1 KiB = 1 slice); the detector row band (f4) can be switched off; frames are backprojected in
     groups of --batch per fused launch (default 32; 1 = one launch per projection; 3 leaves a partial last group of the 8
     frames). Same volume every way; --f16 rounds the filtered frames to half and is held to a looser bound."""
     geo = write_dataset(oracle, tmp_path / "in")
-    run(["--geometry", geo, "--input", tmp_path / "in", "--output", tmp_path / "out", "--name", "kat"] + extra)
+    out = run(["--geometry", geo, "--input", tmp_path / "in", "--output", tmp_path / "out", "--name", "kat"] + extra)
+    # several slabs on one device: the drain thread writes slab k while slab k + 1 is reconstructed in a second volume buffer
+    # (unless --one-volume keeps the reference's one buffer per device)
+    if "--slabs" in extra:
+        assert ("two volume buffers" in out) == ("--one-volume" not in extra), out
     head, vol = F.ddbvf_read(str(tmp_path / "out" / "kat.ddbvf"))
     assert head == F.ddbvf_header_bytes(67, 67, 61)
     want = oracle_volume(oracle, range(8))
