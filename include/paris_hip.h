@@ -107,7 +107,10 @@ void* paris_hip_ctx_stream(paris_hip_ctx* ctx);
 typedef struct paris_hip_fence paris_hip_fence;
 int paris_hip_fence_create(paris_hip_ctx* ctx, paris_hip_fence** out);
 int paris_hip_fence_record(paris_hip_ctx* ctx, paris_hip_fence* fence);
-int paris_hip_fence_wait(paris_hip_ctx* ctx, paris_hip_fence* fence); /* returns at once if never recorded */
+/* returns at once if never recorded. Touches no ctx state (ctx only names the device): a thread other than the ctx's own may wait for a
+ * fence that thread has been told is recorded -- paris.hip's feed and drain threads do (paris_amd/host/paris/reconstruct.h) -- and a fence of
+ * one ctx may be waited for through another ctx of the same device. Every other entry point of a ctx belongs to one thread at a time. */
+int paris_hip_fence_wait(paris_hip_ctx* ctx, paris_hip_fence* fence);
 int paris_hip_fence_destroy(paris_hip_ctx* ctx, paris_hip_fence* fence);
 
 /* ---- memory: make_projection_device / make_volume_device / copy_h2d / copy_d2h
