@@ -670,6 +670,7 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     // default mapping: beyond 1024^2 planes the y tiles are dealt to the XCDs in pairs, in shallow z chunks (order 15: round 3;
     // rounds 1-2 ran a y band per XCD there, order 12); below, z tiles dealt to the XCDs (order 18; volumes of fewer than 8 z tiles,
     // and rounds 1-2: a contiguous run of tiles per XCD, order 5)
+    g.yfast = 0u;
     g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 15u : 18u); // (18 falls back to 5 unless the z tiles divide among the XCDs: settle_order)
     g.store_sc1 = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) == 2 ? 1u : 0u;
     // 4-pixel staging needs every detector row to start 16-byte (half: 8-byte) aligned
@@ -1151,6 +1152,19 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         if(skip)
             break;
         fp.n_proj = n;
+        // The default dealt order hands an XCD y tiles in groups of 32 rows (two 16-row tiles of the single-projection kernel). The fused
+        // kernel's tiles are 4 * fused_vx rows: the same 32 rows are 8 / 4 / 2 of them (orders 17 / 16 / 15). Its tiles stage a detector
+        // box per projection, and tiles 4 rows apart share nine tenths of it: with pairs of 4-row tiles an XCD's L2 saw every box row
+        // about half as often as it was fetched (358 GB per 48-projection launch at 2048^3 against 69 GB of algorithmic bytes)
+        if(ctx->bp_order < 0 && fp.g.order == 15u)
+            fp.g.order = fused_vx == 1 ? 17u : (fused_vx == 2 ? 16u : 15u);
+        // ... and an XCD runs its y tiles fastest, then x: the 128 workgroups resident on an XCD are then 64 y tiles of two x tiles
+        // instead of 4 y tiles of 32 x tiles. Where x runs across the detector (projections near 90 and 270 degrees) every x tile
+        // stages a box of its own and only tiles that differ in y share one; per 48-projection launch at 2048^3 the L2 misses fell
+        // from 378 ... 485 GB to 91 ... 122 GB at those angles (87 against 95 GB near 0 and 180 degrees, where x is the depth), the
+        // mean over the circle from 319 to 102 GB, and the launch got 4 % faster (profiles/r03_ab_fused_traffic.txt)
+        static const bool x_fast = std::getenv("PARIS_FUSED_XFAST") != nullptr; // A/B switch: the old nesting
+        fp.g.yfast = x_fast ? 0u : 1u;
         if(ctx->bp_lds_bytes == 0u) // the fused kernel runs 4 workgroups per CU: a 32 KiB box budget (tools/tune_bp.py --fused: +1.7 %)
             fp.g.lds_floats = 32u * 1024u / sizeof(float);
         fp.proj_stride = static_cast<uint32_t>(p_stride_bytes / px);

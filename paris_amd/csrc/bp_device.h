@@ -51,6 +51,9 @@ namespace
         // The volume holds no -0 (zero-filled by the library and written by backprojections only since: a sum of floats is -0 only
         // if both terms are): adding +0 then changes nothing, and waves whose columns all have Column::none skip the tile
         uint32_t skip_invalid;
+        // dealt orders 14 .. 17: the XCD's y tiles run fastest (then x) instead of x (then the z tile, then y). Set per launch by the
+        // fused kernel, whose co-resident tiles should share their detector boxes (backproject.hip: batch_impl)
+        uint32_t yfast;
     };
 
     struct ColConst
@@ -262,10 +265,20 @@ namespace
             // 4 z tiles: slower; profiles/r03_ab_zdeal.txt).
             const uint32_t xcd = b % 8u;
             uint32_t r = b / 8u;
-            bx = r % g.ntx;
-            r /= g.ntx;
-            by = r % g.nty;
-            bz = (r / g.nty) * 8u + xcd;
+            if(g.yfast != 0u) // (fused kernel: y fastest, see the dealt orders below)
+            {
+                by = r % g.nty;
+                r /= g.nty;
+                bx = r % g.ntx;
+                bz = (r / g.ntx) * 8u + xcd;
+            }
+            else
+            {
+                bx = r % g.ntx;
+                r /= g.ntx;
+                by = r % g.nty;
+                bz = (r / g.nty) * 8u + xcd;
+            }
             return bz < g.ntz;
         }
         if(g.order >= 14u && g.order <= 17u)
@@ -283,12 +296,25 @@ namespace
             const uint32_t zchunk = g.zchunk;
             const uint32_t xcd = b % 8u;
             uint32_t r = b / 8u;
-            bx = r % g.ntx;
-            r /= g.ntx;
-            const uint32_t zl = r % zchunk;
-            r /= zchunk;
-            const uint32_t yb = r % band;
-            bz = (r / band) * zchunk + zl;
+            uint32_t zl, yb;
+            if(g.yfast != 0u) // the XCD's y tiles fastest, then x, then the z tile inside the chunk, then the chunk
+            {
+                yb = r % band;
+                r /= band;
+                bx = r % g.ntx;
+                r /= g.ntx;
+                zl = r % zchunk;
+                bz = (r / zchunk) * zchunk + zl;
+            }
+            else
+            {
+                bx = r % g.ntx;
+                r /= g.ntx;
+                zl = r % zchunk;
+                r /= zchunk;
+                yb = r % band;
+                bz = (r / band) * zchunk + zl;
+            }
             const uint32_t grp = 1u << (g.order - 14u);
             by = (yb / grp) * (8u * grp) + xcd * grp + yb % grp;
             return bz < g.ntz && by < g.nty;
