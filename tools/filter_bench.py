@@ -58,6 +58,13 @@ def main():
         be.set_stage_fusion(True)
         out["fused_one_launch_us"] = timed(two)
         out["fused_one_launch_half_store_us"] = timed(lambda p: B.weight_filter_rows(be, p, det, 0, n, half.data_ptr(), n * 2))
+        # a group of frames per launch (paris_hip_stage_weight_filter_batch: what bench.py's fused leg and the driver use per group)
+        for frames in (8, 16, 48):
+            stack = torch.rand((frames, n, n), device=dev, dtype=torch.float32)
+            torch.cuda.synchronize()
+            per_launch = timed(lambda p, st=stack, k=frames: B.weight_filter_batch(be, st.data_ptr(), n * 4, n * n * 4, k, n, n, det, 0, n))
+            out["group_of_%d_frames_us_per_frame" % frames] = per_launch / frames
+            del stack
         be.set_stage_fusion(False)
         out["fused_GBps_at_8B_per_pixel"] = 8.0 * n * n / (out["fused_one_launch_us"] * 1e-6) / 1e9
         print(json.dumps(out), flush=True)
