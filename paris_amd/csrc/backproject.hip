@@ -1158,12 +1158,15 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         // about half as often as it was fetched (358 GB per 48-projection launch at 2048^3 against 69 GB of algorithmic bytes)
         if(ctx->bp_order < 0 && fp.g.order == 15u)
             fp.g.order = fused_vx == 1 ? 17u : (fused_vx == 2 ? 16u : 15u);
-        // ... and an XCD runs its y tiles fastest, then x: the 128 workgroups resident on an XCD are then 64 y tiles of two x tiles
-        // instead of 4 y tiles of 32 x tiles. Where x runs across the detector (projections near 90 and 270 degrees) every x tile
-        // stages a box of its own and only tiles that differ in y share one; per 48-projection launch at 2048^3 the L2 misses fell
-        // from 378 ... 485 GB to 91 ... 122 GB at those angles (87 against 95 GB near 0 and 180 degrees, where x is the depth), the
-        // mean over the circle from 319 to 102 GB, and the launch got 4 % faster (profiles/r03_ab_fused_traffic.txt)
-        static const bool x_fast = std::getenv("PARIS_FUSED_XFAST") != nullptr; // A/B switch: the old nesting
+        // ... and an XCD runs the eight (four, two) y tiles of one dealt group fastest, then x, then its next group: the 128 workgroups
+        // resident on an XCD are 32 adjacent rows of 16 (32, 64) x tiles instead of 4 y tiles of 32 x tiles. A tile stages one detector
+        // box per projection; where x runs across the detector (projections near 90 and 270 degrees) every x tile has a box of its own
+        // and only tiles that differ in y -- the depth there -- share one, and tiles far apart in depth see it shifted and scaled. Per
+        // 48-projection launch at 2048^3 the L2 misses fell from 378 ... 485 GB to 78 ... 91 GB at those angles (53 against 95 GB near 0
+        // and 180 degrees), the mean over the circle from 319 to 74 GB against 35 GB of compulsory reads, and the launch got 4 % faster
+        // (profiles/r03_ab_fused_traffic.txt). Wider groups cut the misses further (64 rows: 57 GB, 128: 48) but unbalance the XCDs'
+        // shares of skipped tiles: -1 % and -3 %.
+        static const bool x_fast = std::getenv("PARIS_FUSED_XFAST") != nullptr; // A/B switch: the single-projection kernel's nesting
         fp.g.yfast = x_fast ? 0u : 1u;
         if(ctx->bp_lds_bytes == 0u) // the fused kernel runs 4 workgroups per CU: a 32 KiB box budget (tools/tune_bp.py --fused: +1.7 %)
             fp.g.lds_floats = 32u * 1024u / sizeof(float);

@@ -51,8 +51,9 @@ namespace
         // The volume holds no -0 (zero-filled by the library and written by backprojections only since: a sum of floats is -0 only
         // if both terms are): adding +0 then changes nothing, and waves whose columns all have Column::none skip the tile
         uint32_t skip_invalid;
-        // dealt orders 14 .. 17: the XCD's y tiles run fastest (then x) instead of x (then the z tile, then y). Set per launch by the
-        // fused kernel, whose co-resident tiles should share their detector boxes (backproject.hip: batch_impl)
+        // dealt orders 14 .. 17: the y tiles of one dealt group run fastest, then x, then the XCD's next group (order 18: y fastest, then
+        // x) instead of x, then the z tile, then y. Set by the fused kernel's launcher, whose co-resident tiles should share their
+        // detector boxes (backproject.hip: batch_impl)
         uint32_t yfast;
     };
 
@@ -293,16 +294,20 @@ namespace
             // y tiles at any time: a compact window. Pairs keep the banded order's rate where nothing is skipped (0.719 against
             // 0.711 for single tiles) at the same rate with the skip.
             const uint32_t band = dealt_band(g.nty, g.order);
+            const uint32_t grp = 1u << (g.order - 14u);
             const uint32_t zchunk = g.zchunk;
             const uint32_t xcd = b % 8u;
             uint32_t r = b / 8u;
             uint32_t zl, yb;
-            if(g.yfast != 0u) // the XCD's y tiles fastest, then x, then the z tile inside the chunk, then the chunk
+            if(g.yfast != 0u) // the y tiles of a group fastest, then x, then the XCD's next group, then the z tile inside the chunk, then the chunk
             {
-                yb = r % band;
-                r /= band;
+                const uint32_t yl = r % grp;
+                r /= grp;
                 bx = r % g.ntx;
                 r /= g.ntx;
+                const uint32_t ngrp = band / grp;
+                yb = (r % ngrp) * grp + yl;
+                r /= ngrp;
                 zl = r % zchunk;
                 bz = (r / zchunk) * zchunk + zl;
             }
@@ -315,7 +320,6 @@ namespace
                 yb = r % band;
                 bz = (r / band) * zchunk + zl;
             }
-            const uint32_t grp = 1u << (g.order - 14u);
             by = (yb / grp) * (8u * grp) + xcd * grp + yb % grp;
             return bz < g.ntz && by < g.nty;
         }
