@@ -395,6 +395,9 @@ def main():
                     "config-1 job (cpu_baseline_c1, a few seconds of CPU work plus ~20 s of frame synthesis)")
     ap.add_argument("--filter-batch", type=int, default=1, help="fused_extension leg: 1 (default) = the group's frames are weighted and "
                     "filtered by one launch (paris_hip_stage_weight_filter_batch), 0 = one launch per frame")
+    ap.add_argument("--filter-deferral", type=int, default=1, help="deferred_boundary leg: 1 (default) = the filter() of each projection is "
+                    "held back with its weight() and runs on the library's snapshots, one launch per group (paris_hip_set_filter_deferral: "
+                    "what paris::hip switches on); 0 = one weight + filter launch per projection")
     ap.add_argument("--overlap", type=int, default=0, help="deferred_boundary leg: 1 = fused launches of deferred calls on the ctx's "
                     "second stream beside the next group's copies and filters (paris_hip_set_backproject_overlap); 0 (default, the "
                     "library's default) = on the ctx stream")
@@ -692,6 +695,7 @@ def main():
         # ---- the same per-projection calls as the headline, with the library's deferral switched on: every
         # paris_hip_backproject call snapshots its projection, `batch` of them are added by one fused launch
         be.set_backproject_deferral(fb)
+        be.set_filter_deferral(bool(args.filter_deferral) and not f16)
         step(n_proj - fb, fb)
         be.flush()
         torch.cuda.synchronize()
@@ -705,6 +709,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         td = max_over_ranks(time.perf_counter() - td0)
+        be.set_filter_deferral(False)
         be.set_backproject_deferral(1)
         fused["deferred_seconds"] = td
         fused["deferred_host_seconds"] = td_host
@@ -840,8 +845,10 @@ def main():
                 out["deferred_boundary"] = {
                     "what": "the headline's step unchanged -- one paris_hip_backproject call per projection -- with "
                             "paris_hip_set_backproject_deferral(%d): the library snapshots each call's projection and adds %d of "
-                            "them per fused launch (bit-identical volume); what PARIS's per-projection loop gets through paris::hip"
-                            % (fb, fb),
+                            "them per fused launch (bit-identical volume)%s; what PARIS's per-projection loop gets through paris::hip"
+                            % (fb, fb, ", and paris_hip_set_filter_deferral(1): each call pair weight() + filter() is held back and runs "
+                               "on the snapshots, one launch per group" if (args.filter_deferral and not f16) else ""),
+                    "filter_deferral": bool(args.filter_deferral and not f16),
                     "value": voxels_all * fused["deferred_projections"] / fused["deferred_seconds"] / 1e9,
                     "unit": "GVoxel-updates/s",
                     # how long the calls themselves took to return (Python + ctypes + HIP enqueue): close to 1 = the leg is bound

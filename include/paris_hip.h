@@ -306,6 +306,16 @@ int paris_hip_backproject_batch_f16(paris_hip_ctx* ctx, const uint16_t* d_p, siz
  * (src/main.cpp:98-105) runs at the fused kernel's rate. */
 int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t depth);
 int paris_hip_flush(paris_hip_ctx* ctx);
+/* Extension: filter deferral, for small projections whose weight + filter launch is mostly latency (512^2: 7 us alone, 0.9 us as one
+ * of 48 in a group launch). With enable != 0, stage fusion on and a deferral depth > 1, the paris_hip_apply_filter call that
+ * follows a held-back weighting of the same rows is held back as well. If the NEXT call backprojects that projection
+ * (paris_hip_backproject into the deferral ring), the library snapshots the still unfiltered frame and runs weighting + filter on
+ * its snapshots, one launch for the whole group, right before the group's fused backprojection: the volume is bit-identical. Any
+ * other entry point runs the held-back launch first, in place, as if it had never been held. The one thing that changes: after
+ * such a backprojection the caller's projection buffer still holds the UNFILTERED pixels (PARIS's loop, src/main.cpp:98-105,
+ * never looks at a projection again after backprojecting it; a caller that does leaves this off). Off by default; the C++ mirror
+ * paris::hip switches it on. */
+int paris_hip_set_filter_deferral(paris_hip_ctx* ctx, int enable);
 /* Where the fused launch of a full group runs: with enable != 0 on a second stream of the ctx, ordered behind the
  * group's snapshot copies, so that the uploads, weightings and filters of the NEXT group -- which the caller keeps enqueuing on
  * the ctx stream -- execute beside it instead of behind it (what small volumes need: a 256^3 launch of 16 projections takes about

@@ -93,6 +93,7 @@ SIGNATURES = {
     "paris_hip_set_backproject_skip_invalid": (C.c_int, [_vp, C.c_int]),
     "paris_hip_volume_mark_dirty": (C.c_int, [_vp, _vp, _sz]),
     "paris_hip_volume_mark_clean": (C.c_int, [_vp, _vp, _sz]),
+    "paris_hip_set_filter_deferral": (C.c_int, [_vp, C.c_int]),
     "paris_hip_volume_scan_clean": (C.c_int, [_vp, _vp, _sz, C.POINTER(C.c_uint64)]),
     "paris_hip_weight_filter_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _f, _f, _f, _f, _f, _vp, _u32, _vp, _sz]),
     "paris_hip_weight_filter_batch": (C.c_int, [_vp, _vp, _sz, _sz, _u32, _u32, _u32, _u32, _u32, _f, _f, _f, _f, _f, _vp, _u32, _vp, _sz, _sz]),

@@ -375,6 +375,12 @@ class Backend:
         """window of the K that the filter stage wrapper builds: 0 = the reference's ramp, 1 = Shepp-Logan"""
         check(self._L.paris_hip_set_filter_window(self._ctx, window), "paris_hip_set_filter_window")
 
+    def set_filter_deferral(self, enable):
+        """paris_hip_set_filter_deferral: with stage fusion and a deferral depth > 1, the filter() that follows a weight() is held back
+        too and runs on the library's snapshot, a group per launch, if the next call backprojects that projection (whose buffer then
+        keeps its unfiltered pixels); bit-identical volume"""
+        check(self._L.paris_hip_set_filter_deferral(self._ctx, int(bool(enable))), "paris_hip_set_filter_deferral")
+
     def set_backproject_deferral(self, depth):
         """depth > 1: backproject() calls are snapshotted and added by one fused launch per `depth` calls (bit-identical)"""
         check(self._L.paris_hip_set_backproject_deferral(self._ctx, depth), "paris_hip_set_backproject_deferral")

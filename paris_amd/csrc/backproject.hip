@@ -839,6 +839,50 @@ int paris_hip_launch_deferred(paris_hip_ctx* ctx)
         PARIS_HIP_TRY(hipStreamWaitEvent(ctx->bp_stream, ctx->bp_ring_ready, 0));
         ctx->stream = ctx->bp_stream;
     }
+    // slots that took a held-back weighting + filter along (filter deferral): one launch for the group when every slot asks for the
+    // same rows with the same constants, a launch per slot otherwise; on the stream the fused launch follows on
+    {
+        uint32_t flagged = 0;
+        bool uniform = true;
+        for(uint32_t i = 0; i < n && i < ctx->defer_wf.size(); ++i)
+        {
+            const auto& w = ctx->defer_wf[i];
+            if(!w.active)
+                continue;
+            ++flagged;
+            const auto& w0 = ctx->defer_wf[0];
+            uniform = uniform && w0.active && w.dim_x == w0.dim_x && w.row_first == w0.row_first && w.row_count == w0.row_count
+                      && std::memcmp(&w.h_min, &w0.h_min, 5u * sizeof(float)) == 0 && w.d_kp == w0.d_kp && w.plan == w0.plan
+                      && w.filter_size == w0.filter_size;
+        }
+        const size_t slot_bytes = ctx->defer_pitch * ctx->defer_dim_y;
+        const uint32_t pitch_f = static_cast<uint32_t>(ctx->defer_pitch / sizeof(float));
+        int wrc = PARIS_HIP_SUCCESS;
+        if(flagged == n && uniform && n > 0)
+        {
+            const auto& w = ctx->defer_wf[0];
+            float* rows = reinterpret_cast<float*>(const_cast<char*>(ring) + static_cast<size_t>(w.row_first) * ctx->defer_pitch);
+            wrc = paris_hip_fused_filter_launch(ctx, rows, pitch_f, w.dim_x, w.row_count, w.row_first, true, w.h_min, w.v_min, w.d_sd, w.l_px_row,
+                                                w.l_px_col, w.d_kp, w.plan, w.filter_size, nullptr, 0u, n, static_cast<uint32_t>(slot_bytes / sizeof(float)), 0u);
+        }
+        else
+            for(uint32_t i = 0; i < n && i < ctx->defer_wf.size() && wrc == PARIS_HIP_SUCCESS; ++i)
+            {
+                const auto& w = ctx->defer_wf[i];
+                if(!w.active)
+                    continue;
+                float* rows = reinterpret_cast<float*>(const_cast<char*>(ring) + i * slot_bytes + static_cast<size_t>(w.row_first) * ctx->defer_pitch);
+                wrc = paris_hip_fused_filter_launch(ctx, rows, pitch_f, w.dim_x, w.row_count, w.row_first, true, w.h_min, w.v_min, w.d_sd, w.l_px_row,
+                                                    w.l_px_col, w.d_kp, w.plan, w.filter_size, nullptr, 0u);
+            }
+        for(auto& w : ctx->defer_wf)
+            w.active = false;
+        if(wrc != PARIS_HIP_SUCCESS)
+        {
+            ctx->stream = caller_stream;
+            return wrc;
+        }
+    }
     ctx->defer_count = 0; // before the launch: batch_impl may fall back to single launches, which must not be deferred again
     ctx->defer_depth = 1;
     const int rc = batch_impl(ctx, ring, ctx->defer_f16, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
@@ -878,14 +922,34 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
                              const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
                              const paris_region_of_interest* roi, float sin_phi, float cos_phi, float delta_s, float delta_t)
 {
+    // Filter deferral: weighting and row filter of exactly this projection are still held back (paris_hip_apply_filter). They move
+    // into the ring slot with the unfiltered snapshot and run there, with the rest of the group, before the fused launch.
+    paris_hip_ctx::pending_weight_t taken{};
+    {
+        auto& w = ctx->pending_weight;
+        if(w.active && w.filter && !f16 && w.d_p == d_p && w.pitch == p_pitch && w.dim_x == p_dim_x && w.dim_y == p_dim_y)
+        {
+            taken = w;
+            w.active = false;
+            w.filter = false;
+        }
+    }
+    const auto give_back = [&](int rc) { // the call fails or has nothing to add: the filter was still asked for
+        if(taken.active)
+        {
+            ctx->pending_weight = taken;
+            (void)paris_hip_flush_pending_weight(ctx);
+        }
+        return rc;
+    };
     // the checks of an immediate call, so that a bad argument is reported by the call that made it
     BpParams g;
     bool fd = false, skip = false;
     if(int rc = fill_params(ctx, d_p, f16, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
                             enable_roi, roi, sin_phi, cos_phi, delta_s, delta_t, g, fd, skip))
-        return rc;
+        return give_back(rc);
     if(skip)
-        return paris_hip_finish(ctx);
+        return give_back(paris_hip_finish(ctx));
     const size_t px = f16 ? sizeof(uint16_t) : sizeof(float);
     const paris_region_of_interest no_roi{};
     const paris_region_of_interest& r = enable_roi ? *roi : no_roi;
@@ -898,7 +962,7 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
     if(!same)
     {
         if(int rc = paris_hip_flush_deferred(ctx))
-            return rc;
+            return give_back(rc);
         if(ctx->defer_dim_x != p_dim_x || ctx->defer_dim_y != p_dim_y || ctx->defer_slots < ctx->defer_depth || ctx->defer_f16 != f16)
         {
             if(ctx->defer_ring != nullptr)
@@ -924,6 +988,7 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
         ctx->key_delta_t = delta_t;
         ctx->defer_sin.assign(ctx->defer_depth, 0.f);
         ctx->defer_cos.assign(ctx->defer_depth, 0.f);
+        ctx->defer_wf.assign(ctx->defer_depth, paris_hip_ctx::pending_weight_t{});
     }
     const uint32_t half = ctx->defer_half;
     if(ctx->defer_count == 0 && ctx->bp_half_busy[half])
@@ -942,6 +1007,9 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
         return rc;
     ctx->defer_sin[ctx->defer_count] = sin_phi;
     ctx->defer_cos[ctx->defer_count] = cos_phi;
+    if(ctx->defer_wf.size() < ctx->defer_depth)
+        ctx->defer_wf.resize(ctx->defer_depth);
+    ctx->defer_wf[ctx->defer_count] = taken; // (inactive: the snapshot is filtered already)
     if(++ctx->defer_count == ctx->defer_depth)
     {
         if(int rc = paris_hip_launch_deferred(ctx)) // no join: the caller's next calls run beside the launch

@@ -555,8 +555,21 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
     {
         // a weighting held back for exactly these rows (stage fusion) rides along in the load
         auto& w = ctx->pending_weight;
+        if(w.active && w.filter) // a filter is held back already (filter deferral): it comes first
+            if(int rc = paris_hip_flush_pending_weight(ctx))
+                return rc;
         const bool fuse = w.active && w.pitch == pitch && w.dim_x == dim_x && w.row_count == dim_y
                           && reinterpret_cast<char*>(w.d_p) + static_cast<size_t>(w.row_first) * w.pitch == reinterpret_cast<char*>(d_p);
+        if(fuse && ctx->filter_deferral != 0 && ctx->defer_depth > 1u && !(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS))
+        {
+            // filter deferral: held back with the weighting. A backprojection of this projection takes both along into its ring slot
+            // (backproject.hip: defer_backproject); anything else runs them first, in place (paris_hip_flush_pending_weight)
+            w.filter = true;
+            w.d_kp = info->d_kp;
+            w.plan = plan;
+            w.filter_size = filter_size;
+            return PARIS_HIP_SUCCESS;
+        }
         if(fuse)
             w.active = false;
         else if(int rc = paris_hip_flush_pending_weight(ctx))

@@ -82,7 +82,18 @@ struct paris_hip_ctx
         size_t pitch = 0;
         uint32_t dim_x = 0, dim_y = 0, row_first = 0, row_count = 0;
         float h_min = 0.f, v_min = 0.f, d_sd = 0.f, l_px_row = 0.f, l_px_col = 0.f;
+        // filter deferral (below): the row filter that followed on the same rows is held back too
+        bool filter = false;
+        const float* d_kp = nullptr;
+        const paris_hip_fft_plan* plan = nullptr;
+        uint32_t filter_size = 0;
     } pending_weight;
+    // Filter deferral (paris_hip_set_filter_deferral; needs stage fusion and a backprojection deferral depth > 1): the
+    // paris_hip_apply_filter call that would run the one weight + filter launch is held back as well. If the next call backprojects
+    // those rows' projection, the UNFILTERED frame is snapshotted into the deferral ring and weighting + filter run on the ring, one
+    // launch for the whole group, right before the fused backprojection; any other call runs the held-back launch first, in place.
+    int filter_deferral = 0;
+    std::vector<pending_weight_t> defer_wf; // per ring slot of the current group: the weight + filter it still needs
     // dedicated upload stream + ring of events ordering the compute stream behind each upload (paris_hip_upload_projection)
     hipStream_t upload_stream = nullptr;
     std::vector<hipEvent_t> upload_events;

@@ -45,7 +45,16 @@ int paris_hip_flush_pending_weight(paris_hip_ctx* ctx)
         return PARIS_HIP_SUCCESS;
     const auto w = ctx->pending_weight;
     ctx->pending_weight.active = false;
+    ctx->pending_weight.filter = false;
     PARIS_HIP_TRY(hipSetDevice(ctx->device));
+    if(w.filter) // weighting and row filter were both held back (filter deferral): the one launch apply_filter would have made
+    {
+        float* rows = reinterpret_cast<float*>(reinterpret_cast<char*>(w.d_p) + static_cast<size_t>(w.row_first) * w.pitch);
+        if(int rc = paris_hip_fused_filter_launch(ctx, rows, static_cast<uint32_t>(w.pitch / sizeof(float)), w.dim_x, w.row_count, w.row_first, true,
+                                                  w.h_min, w.v_min, w.d_sd, w.l_px_row, w.l_px_col, w.d_kp, w.plan, w.filter_size, nullptr, 0u))
+            return rc;
+        return paris_hip_note_projection_use(ctx, rows, w.pitch * w.row_count);
+    }
     if(int rc = weight_rows_now(ctx, w.d_p, w.pitch, w.dim_x, w.row_first, w.row_count, w.h_min, w.v_min, w.d_sd, w.l_px_row, w.l_px_col))
         return rc;
     return static_cast<int>(hipGetLastError());
@@ -69,6 +78,7 @@ extern "C" int paris_hip_weight_rows(paris_hip_ctx* ctx, float* d_p, size_t pitc
         // held back: the filter call that follows weights in its load (one launch, 8 instead of 16 bytes of traffic per pixel)
         auto& w = ctx->pending_weight;
         w.active = true;
+        w.filter = false;
         w.d_p = d_p;
         w.pitch = pitch;
         w.dim_x = dim_x;
@@ -91,6 +101,16 @@ extern "C" int paris_hip_weight(paris_hip_ctx* ctx, float* d_p, size_t pitch, ui
                                 float h_min, float v_min, float d_sd, float l_px_row, float l_px_col)
 {
     return paris_hip_weight_rows(ctx, d_p, pitch, dim_x, dim_y, 0u, dim_y, h_min, v_min, d_sd, l_px_row, l_px_col);
+}
+
+extern "C" int paris_hip_set_filter_deferral(paris_hip_ctx* ctx, int enable)
+{
+    if(ctx == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(int rc = paris_hip_flush_deferred(ctx)) // (runs a held-back weighting / filter as well)
+        return rc;
+    ctx->filter_deferral = enable ? 1 : 0;
+    return PARIS_HIP_SUCCESS;
 }
 
 extern "C" int paris_hip_set_stage_fusion(paris_hip_ctx* ctx, int enable)

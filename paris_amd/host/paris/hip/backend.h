@@ -22,6 +22,13 @@
 #ifndef PARIS_HIP_STAGE_FUSION
 #define PARIS_HIP_STAGE_FUSION 1
 #endif
+// 1 (default): the apply_filter() of that pair is held back too when the projection is backprojected next, and weighting + filter
+// run on the library's snapshots, one launch per group of deferred backprojections (paris_hip_set_filter_deferral: what small
+// projections need, whose single launches are mostly latency). The projection's own buffer then keeps its unfiltered pixels; PARIS's
+// loop destroys it right after backproject() (src/main.cpp:98-105). 0: the filter runs when it is called.
+#ifndef PARIS_HIP_FILTER_DEFERRAL
+#define PARIS_HIP_FILTER_DEFERRAL 1
+#endif
 // 1: every backend call returns after its work has finished, like the reference's backends (stream sync before return:
 // src/cuda/weighting.cu:72, filtering.cu:260, backprojection.cu:236). 0 (default): calls enqueue and return; only the
 // copies to the host wait. The call sequence of src/main.cpp:98-105 observes results through copy_d2h alone, and the
@@ -126,6 +133,7 @@ namespace paris
                 // observes the volume (copy_d2h, free): see paris_hip_set_backproject_deferral. 1 = one launch per call.
                 detail::construction_check(paris_hip_set_backproject_deferral(c, PARIS_HIP_BACKPROJECT_DEFERRAL), "set_device()");
                 detail::construction_check(paris_hip_set_stage_fusion(c, PARIS_HIP_STAGE_FUSION), "set_device()");
+                detail::construction_check(paris_hip_set_filter_deferral(c, PARIS_HIP_FILTER_DEFERRAL), "set_device()");
                 it = s.per_device.emplace(d, std::unique_ptr<paris_hip_ctx, detail::ctx_deleter>{c}).first;
             }
             s.current = it->second.get();

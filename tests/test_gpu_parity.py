@@ -1081,6 +1081,80 @@ def test_deferred_backprojection_is_bit_identical(oracle, kat_golden, depth, lau
         B.backproject(abe, d_p, d_a, 0, det, vg, False, True, roi)      # left pending: ctx destruction drops it
 
 
+@pytest.mark.parametrize("depth,band", [(5, None), (3, (6, 21)), (64, None)])
+def test_filter_deferral_is_bit_identical(oracle, depth, band):
+    """paris_hip_set_filter_deferral: with stage fusion and backprojection deferral on, the filter() that follows a weight() is held
+    back as well; a backproject() of that projection takes both into its ring slot (the UNFILTERED frame is snapshotted) and the
+    group's weighting + filter run as one launch before the fused backprojection. One device buffer is refilled for every
+    projection. Same volume bit for bit as with the switch off; every other follow-up call runs the held-back launch first, in
+    place; after a deferred backprojection the caller's buffer still holds the raw pixels (the documented difference)."""
+    g = (512, 40, 0.2, 0.2, 1.25, -0.5, 300, 200, 7.0)   # 512 pixels per row: a 1024-point filter, the fused weight + filter kernel
+    det = B.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(96, 80, 24, nat.l_vx_x * 4.0, nat.l_vx_x * 4.5, nat.l_vx_z * 1.2)
+    raws = [oracle.lcg_projection(512, 40, 40 + i) for i in range(11)]
+    first, count = band if band is not None else (0, 40)
+
+    def run(hold):
+        with B.Backend(0, synchronous=False) as abe:
+            abe.set_stage_fusion(True)
+            abe.set_backproject_deferral(depth)
+            abe.set_filter_deferral(hold)
+            L, ctx = abe._L, abe._ctx
+            d_p = abe.make_projection_device(512, 40)
+            d_v = abe.make_volume_device(96, 80, 24)
+            seen = {}
+            for i, raw in enumerate(raws):
+                h = np.ascontiguousarray(raw)
+                assert L.paris_hip_memcpy_projection_h2d(ctx, d_p.ptr, d_p.pitch, h.ctypes.data, 512 * 4, 512, 40) == 0
+                d_p.idx = i
+                if i == 4:                      # the one-call form: nothing is held, the slot is filtered already (mixed group)
+                    B.weight_filter_rows(abe, d_p, det, first, count)
+                else:
+                    B.weight_rows(abe, d_p, det, first, count)
+                    B.filter_rows(abe, d_p, det, first, count)
+                if i == 6:                      # the projection is read back instead: the held-back launch runs first, in place
+                    seen["filtered"] = to_host(abe, d_p).copy()
+                if i == 8:                      # a second filter on the same rows: the first one must not be lost
+                    B.filter_rows(abe, d_p, det, first, count)
+                B.backproject(abe, d_p, d_v, 3, det, vg, False, False, None)
+                if i == 2:
+                    seen["after"] = to_host(abe, d_p).copy()   # (flushes the group; the buffer: raw with the switch, filtered without)
+            B.weight_rows(abe, d_p, det, first, count)
+            B.filter_rows(abe, d_p, det, first, count)         # held and never backprojected: dropped with the buffer
+            abe.free(d_p)
+            vol = volume_to_host(abe, d_v)
+            return vol, seen
+
+    want, seen_off = run(False)
+    got, seen_on = run(True)
+    assert_bit_equal(got, want)
+    assert np.abs(want).max() > 0
+    assert np.array_equal(seen_on["filtered"].view(np.uint32), seen_off["filtered"].view(np.uint32))
+    # the documented difference: the buffer of a projection whose filter went into the ring keeps its raw pixels
+    assert np.array_equal(seen_on["after"], raws[2]) and not np.array_equal(seen_off["after"], raws[2])
+    # and against the oracle's pipeline (FFT rounding only)
+    odet = oracle.DetectorGeometry(*g)
+    ovg = oracle.VolumeGeometry(96, 80, 24, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    fs = oracle.filter_size(512)
+    k = oracle.make_filter(fs, odet.l_px_row)
+    ref = np.zeros((24, 80, 96), np.float32)
+    for i, raw in enumerate(raws):
+        p = raw.copy()
+        oracle.weight(p, odet)
+        oracle.apply_filter(p, k, fs)
+        if i == 8:
+            oracle.apply_filter(p, k, fs)
+        if band is not None:   # rows outside the band stay raw on the GPU; the slab below only reads rows inside it
+            q = raw.copy()
+            q[first:first + count] = p[first:first + count]
+            p = q
+        sn, cs, ds, dt = oracle.backproject_constants(odet, i)
+        oracle.backproject(ref, p, 3, odet, ovg, sn, cs, ds, dt, None)
+    if band is None:
+        assert np.max(np.abs(got - ref)) <= FILTER_TOL * np.abs(ref).max()
+
+
 # ---- the whole hot path ------------------------------------------------------------------------------------------
 
 def test_pipeline_against_oracle(be, oracle, kat_golden):
