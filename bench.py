@@ -845,7 +845,7 @@ def main():
                 out["deferred_boundary"] = {
                     "what": "the headline's step unchanged -- one paris_hip_backproject call per projection -- with "
                             "paris_hip_set_backproject_deferral(%d): the library snapshots each call's projection and adds %d of "
-                            "them per fused launch (bit-identical volume)%s; what PARIS's per-projection loop gets through paris::hip"
+                            "them per fused launch (bit-identical volume)%s; the call sequence of PARIS's per-projection loop with the projections resident on the device"
                             % (fb, fb, ", and paris_hip_set_filter_deferral(1): each call pair weight() + filter() is held back and runs "
                                "on the snapshots, one launch per group" if (args.filter_deferral and not f16) else ""),
                     "filter_deferral": bool(args.filter_deferral and not f16),

@@ -22,12 +22,14 @@
 #ifndef PARIS_HIP_STAGE_FUSION
 #define PARIS_HIP_STAGE_FUSION 1
 #endif
-// 1 (default): the apply_filter() of that pair is held back too when the projection is backprojected next, and weighting + filter
-// run on the library's snapshots, one launch per group of deferred backprojections (paris_hip_set_filter_deferral: what small
-// projections need, whose single launches are mostly latency). The projection's own buffer then keeps its unfiltered pixels; PARIS's
-// loop destroys it right after backproject() (src/main.cpp:98-105). 0: the filter runs when it is called.
+// 1: the apply_filter() of that pair is held back too when the projection is backprojected next, and weighting + filter run on the
+// library's snapshots, one launch per group of deferred backprojections (paris_hip_set_filter_deferral: what small projections
+// need when the GPU is the limit -- their single launches are mostly latency). The projection's own buffer then keeps its
+// unfiltered pixels; PARIS's loop destroys it right after backproject() (src/main.cpp:98-105). 0 (default): the filter runs when
+// it is called -- PARIS's own loop allocates, fills and uploads a pageable host projection per iteration and is bound by that, so
+// the switch buys it nothing (512^2: 408 against 398-433 GVox/s, 1024^2: 1084 against 1074-1099, same box interleaved).
 #ifndef PARIS_HIP_FILTER_DEFERRAL
-#define PARIS_HIP_FILTER_DEFERRAL 1
+#define PARIS_HIP_FILTER_DEFERRAL 0
 #endif
 // 1: every backend call returns after its work has finished, like the reference's backends (stream sync before return:
 // src/cuda/weighting.cu:72, filtering.cu:260, backprojection.cu:236). 0 (default): calls enqueue and return; only the
