@@ -315,7 +315,8 @@ int paris_hip_flush(paris_hip_ctx* ctx);
  * such a backprojection the caller's projection buffer still holds the UNFILTERED pixels (PARIS's loop, src/main.cpp:98-105,
  * never looks at a projection again after backprojecting it; a caller that does leaves this off). Off by default, also in the C++
  * mirror paris::hip (macro PARIS_HIP_FILTER_DEFERRAL): it pays where the GPU's small launches are the limit (bench.py's deferred
- * leg at config 1: 706 -> 913 GVox/s), not where the host loop is (PARIS's own per-projection allocate / fill / upload). */
+ * leg at config 1: 706 -> 913 GVox/s), little where the host loop is as well (PARIS's own per-projection allocate / fill / upload:
+ * +3 % at 512^2, nothing at 1024^2). */
 int paris_hip_set_filter_deferral(paris_hip_ctx* ctx, int enable);
 /* Where the fused launch of a full group runs: with enable != 0 on a second stream of the ctx, ordered behind the
  * group's snapshot copies, so that the uploads, weightings and filters of the NEXT group -- which the caller keeps enqueuing on

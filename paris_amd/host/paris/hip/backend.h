@@ -26,8 +26,9 @@
 // library's snapshots, one launch per group of deferred backprojections (paris_hip_set_filter_deferral: what small projections
 // need when the GPU is the limit -- their single launches are mostly latency). The projection's own buffer then keeps its
 // unfiltered pixels; PARIS's loop destroys it right after backproject() (src/main.cpp:98-105). 0 (default): the filter runs when
-// it is called -- PARIS's own loop allocates, fills and uploads a pageable host projection per iteration and is bound by that, so
-// the switch buys it nothing (512^2: 408 against 398-433 GVox/s, 1024^2: 1084 against 1074-1099, same box interleaved).
+// it is called -- PARIS's own loop allocates, fills and uploads a host projection per iteration and is bound by that as much as by
+// the GPU, so the switch buys it little (1536 projections of 512^2: 906-911 against 876-882 GVox/s; 720 of 1024^2: 1299-1303
+// against 1297-1299; same box interleaved), not enough to change what the caller's buffer holds behind its back.
 #ifndef PARIS_HIP_FILTER_DEFERRAL
 #define PARIS_HIP_FILTER_DEFERRAL 0
 #endif
