@@ -235,7 +235,7 @@ namespace paris
         }
 
         // Large detectors: halve the frames per group until the driver's buffers take at most a quarter of the smallest
-        // device's free memory (8192^2 frames: 32 slots would be 8 GiB of device frames plus as much pinned host memory)
+        // device's free memory (8192^2 frames: 64 slots would be 16 GiB of device frames plus as much pinned host memory)
         inline auto fit_batch(program_options po, int n_dev) -> program_options
         {
             std::size_t smallest = ~std::size_t{0};
