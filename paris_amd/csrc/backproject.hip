@@ -670,7 +670,14 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     // default mapping: beyond 1024^2 planes the y tiles are dealt to the XCDs in pairs, in shallow z chunks (order 15: round 3;
     // rounds 1-2 ran a y band per XCD there, order 12); below, z tiles dealt to the XCDs (order 18; volumes of fewer than 8 z tiles,
     // and rounds 1-2: a contiguous run of tiles per XCD, order 5)
-    g.yfast = 0u; // (y tiles fastest is for the fused kernel's box sharing; the volume stream of this kernel loses with it: 2048^3 0.772 -> 0.662, 1024^3 0.743 -> 0.567)
+    {
+        // nesting inside the dealt orders (BpParams::yfast): deep volumes run a group's y tiles before the next z tile (2048^3: 0.7754 ->
+        // 0.7774, 0.7757 -> 0.7784; the 2048^3 ROI of config 5: 0.7387 -> 0.7396, 0.7384 -> 0.7400), a 256-slice slab keeps the z tile
+        // first (0.7584 -> 0.7565, 0.7572 -> 0.7540 with the other nesting); same device, interleaved, profiles/r03_ab_tile_order.txt
+        static const int tile_nest = std::getenv("PARIS_TILE_NEST") ? std::atoi(std::getenv("PARIS_TILE_NEST")) : -1; // A/B switch
+        g.yfast = tile_nest >= 0 ? static_cast<uint32_t>(tile_nest) : (v_dim_z > 512u ? 2u : 0u);
+    }
+    // (y tiles fastest is for the fused kernel's box sharing; the volume stream of this kernel loses with it: 2048^3 0.772 -> 0.662, 1024^3 0.743 -> 0.567)
     g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 15u : 18u); // (18 falls back to 5 unless the z tiles divide among the XCDs: settle_order)
     g.store_sc1 = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) == 2 ? 1u : 0u;
     // 4-pixel staging needs every detector row to start 16-byte (half: 8-byte) aligned

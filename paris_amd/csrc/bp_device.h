@@ -51,9 +51,12 @@ namespace
         // The volume holds no -0 (zero-filled by the library and written by backprojections only since: a sum of floats is -0 only
         // if both terms are): adding +0 then changes nothing, and waves whose columns all have Column::none skip the tile
         uint32_t skip_invalid;
-        // dealt orders 14 .. 17: the y tiles of one dealt group run fastest, then x, then the XCD's next group (order 18: y fastest, then
-        // x) instead of x, then the z tile, then y. Set by the fused kernel's launcher, whose co-resident tiles should share their
-        // detector boxes (backproject.hip: batch_impl)
+        // Nesting inside the dealt orders 14 .. 17. 0: x tiles fastest, then the z tile inside the chunk, then the XCD's y tiles, then
+        // the chunk (round 3's first form). 2: x fastest, then the y tiles of one dealt group, then the z tile, then the XCD's next
+        // group -- the single-projection kernel's default: the resident set of an XCD is 32 adjacent rows of every x tile and two z
+        // tiles instead of 16 rows and four (2048^3, four interleaved pairs on two devices: +0.2 ... +0.3 % of the HBM fraction). 1: the
+        // y tiles of one dealt group fastest, then x, then the XCD's next group (order 18: y fastest, then x) -- the fused kernel,
+        // whose co-resident tiles should share their detector boxes (backproject.hip: batch_impl)
         uint32_t yfast;
     };
 
@@ -266,7 +269,7 @@ namespace
             // 4 z tiles: slower; profiles/r03_ab_zdeal.txt).
             const uint32_t xcd = b % 8u;
             uint32_t r = b / 8u;
-            if(g.yfast != 0u) // (fused kernel: y fastest, see the dealt orders below)
+            if(g.yfast == 1u) // (fused kernel: y fastest, see the dealt orders below)
             {
                 by = r % g.nty;
                 r /= g.nty;
@@ -299,7 +302,19 @@ namespace
             const uint32_t xcd = b % 8u;
             uint32_t r = b / 8u;
             uint32_t zl, yb;
-            if(g.yfast != 0u) // the y tiles of a group fastest, then x, then the XCD's next group, then the z tile inside the chunk, then the chunk
+            if(g.yfast == 2u) // x fastest, then the y tiles of a group, then the z tile inside the chunk, then the XCD's next group, then the chunk
+            {
+                bx = r % g.ntx;
+                r /= g.ntx;
+                const uint32_t yl = r % grp;
+                r /= grp;
+                zl = r % zchunk;
+                r /= zchunk;
+                const uint32_t ngrp = band / grp;
+                yb = (r % ngrp) * grp + yl;
+                bz = (r / ngrp) * zchunk + zl;
+            }
+            else if(g.yfast == 1u) // the y tiles of a group fastest, then x, then the XCD's next group, then the z tile inside the chunk, then the chunk
             {
                 const uint32_t yl = r % grp;
                 r /= grp;
