@@ -515,6 +515,19 @@ def test_backproject_every_tile_order_bit_exact(be, oracle, order, tz, dims):
         be.set_backproject_order()
 
 
+def test_deep_volume_nesting_on_small_volumes():
+    """Volumes deeper than 512 slices run the dealt orders with another nesting (BpParams::yfast = 2: a dealt group's y tiles before
+    the next z tile); the library reads PARIS_TILE_NEST once per process, so the every-order cases above -- uneven tile counts,
+    padding workgroups, every dealt group size, the fused batch beside them -- are run once more in a child process with that
+    nesting forced on their small volumes."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PARIS_TILE_NEST="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "every_tile_order", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("tz,order,unroll", [(4, 12, 1), (8, 12, 2), (16, 5, 2), (2, 8, 1)])
 def test_backproject_two_pass_variant_bit_exact(be, oracle, tz, order, unroll):
     """Variant 5: the column constants of the whole (x, y) plane are computed once per projection by a first kernel and read by
