@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fused backprojection launch time by view angle: 16 consecutive projections (0.25 degrees apart) starting at each given angle,
+"""Fused backprojection launch time by view angle: --batch consecutive projections (0.25 degrees apart) starting at each given angle,
 on a 2048 x 2048 x --slices slab of the 2048^3 grid. GPU box only."""
 import argparse
 import json
@@ -17,8 +17,9 @@ ap.add_argument("--angles", default="0,15,30,45,60,75,90,135,180,225,270,315")
 ap.add_argument("--vx", type=int, default=0)
 ap.add_argument("--tz", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--batch", type=int, default=48)
 args = ap.parse_args()
-n, P = 2048, 16
+n, P = 2048, args.batch
 det = B.DetectorGeometry(n, n, 0.2, 0.2, 0, 0, 500, 500, 0.25)
 nat = B.calculate_volume_geometry(det)
 vg = B.VolumeGeometry(n, n, n, nat.l_vx_x, nat.l_vx_x, nat.l_vx_x)
