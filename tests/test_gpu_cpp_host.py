@@ -84,6 +84,24 @@ def test_cpp_loop_full_pipeline(tmp_path, gold):
     assert np.max(np.abs(got - want)) <= 1e-5 * np.abs(want).max()
 
 
+def test_cpp_loop_with_filter_deferral_is_bit_identical(tmp_path):
+    """PARIS_HIP_FILTER_DEFERRAL=1 (paris_hip_demo_filter_deferral): through the C++ mirror's unchanged load / weight / filter /
+    backproject loop the filter() of every projection is held back with its weight() and runs on the library's snapshots, a group
+    per launch. A 512-pixel detector row (1024-point filter: the fused weight + filter kernel), 60 projections (one full group of
+    48 and a partial one), two slabs: the volume equals the default build's bit for bit."""
+    args = ["512", "24", "0.2", "0.2", "0.5", "-0.25", "300", "200", "6", "60"]
+    vols = []
+    for exe in (DEMO, DEMO + "_filter_deferral"):
+        if not os.path.exists(exe):
+            pytest.fail("%s missing: run __graft_entry__.build()" % exe)
+        out = tmp_path / (os.path.basename(exe) + ".raw")
+        r = subprocess.run([exe] + args + ["lcg", str(out), "--slabs", "2"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        vols.append(np.fromfile(out, np.float32))
+    assert vols[0].size > 0 and np.abs(vols[0]).max() > 0
+    assert np.array_equal(vols[0].view(np.uint32), vols[1].view(np.uint32))
+
+
 def test_flush_rules_at_config3_size():
     """the deferred boundary (16 backproject() calls per fused launch) and the held-back weight() through the
     C++ mirror paris::hip on the 2048^2 detector / 2048^3 grid of BASELINE config 3, with every observer that must flush
