@@ -306,6 +306,9 @@ int paris_hip_backproject_batch_f16(paris_hip_ctx* ctx, const uint16_t* d_p, siz
  * (src/main.cpp:98-105) runs at the fused kernel's rate. */
 int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t depth);
 int paris_hip_flush(paris_hip_ctx* ctx);
+/* How many projections are pending right now and into which volume (NULL when none): what a wrapper that lends the library memory
+ * it does not own needs to decide whether a last paris_hip_flush is still safe (paris_amd.backend.Backend.close). */
+int paris_hip_pending_backprojections(paris_hip_ctx* ctx, uint32_t* count, void** d_v);
 /* Extension: filter deferral, for small projections whose weight + filter launch is mostly latency (512^2: 7 us alone, 0.9 us as one
  * of 48 in a group launch). With enable != 0, stage fusion on and a deferral depth > 1, the paris_hip_apply_filter call that
  * follows a held-back weighting of the same rows is held back as well. If the NEXT call backprojects that projection
@@ -427,6 +430,18 @@ int paris_hip_set_backproject_vector_staging(paris_hip_ctx* ctx, int enable);
 /* Runs (or looks up) the exhaustive check for one divisor: *exact = 1 when multiply + 2 FMA reproduces
  * x / divisor - 0.5 for every fp32 x (see above). */
 int paris_hip_fast_division_is_exact(paris_hip_ctx* ctx, float divisor, int* exact);
+/* Two more hand-expanded IEEE sequences, each used only after the device has compared it with the compiler's correctly rounded
+ * operation for EVERY fp32 operand a launch can produce (once per process, device and operand range; microseconds):
+ *  - the two per-column divisions d_sd / (s + d_so), d_so / (s + d_so) of the backprojection (src/openmp/backprojection.cpp:125,139)
+ *    share one refined reciprocal; checked for every denominator in [0.09, 1.92] x d_so, the range the library first proves the
+ *    launch stays in (otherwise, or on any mismatch, both are plain IEEE divisions). *exact = 1: both quotients have the IEEE bits.
+ *  - the weighting's d_sd / sqrt(q) (src/openmp/weighting.cpp:52) inside the one-launch weight + filter; checked for every radicand
+ *    q in [q_lo, q_hi] (the library asks for [d_sd^2, largest radicand of the rows], widened a little).
+ * paris_hip_set_lean_validation(ctx, 0) makes the kernels trust the range tests alone (rounds 2-3 behaviour; for A/B and for testing
+ * the validators). Results never depend on any of this. */
+int paris_hip_lean_division_is_exact(paris_hip_ctx* ctx, float d_sd, float d_so, int* exact);
+int paris_hip_lean_weighting_is_exact(paris_hip_ctx* ctx, float d_sd, float q_lo, float q_hi, int* exact);
+int paris_hip_set_lean_validation(paris_hip_ctx* ctx, int enable);
 
 #ifdef __cplusplus
 }

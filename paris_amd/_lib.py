@@ -121,6 +121,10 @@ SIGNATURES = {
     "paris_hip_stage_weight_filter_rows": (C.c_int, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _P(DetectorGeometry), _vp, _sz]),
     "paris_hip_set_backproject_deferral": (C.c_int, [_vp, _u32]),
     "paris_hip_flush": (C.c_int, [_vp]),
+    "paris_hip_lean_division_is_exact": (C.c_int, [_vp, _f, _f, _P(C.c_int)]),
+    "paris_hip_lean_weighting_is_exact": (C.c_int, [_vp, _f, _f, _f, _P(C.c_int)]),
+    "paris_hip_set_lean_validation": (C.c_int, [_vp, C.c_int]),
+    "paris_hip_pending_backprojections": (C.c_int, [_vp, _P(_u32), _P(C.c_void_p)]),
     "paris_hip_set_backproject_overlap": (C.c_int, [_vp, C.c_int]),
     "paris_hip_slab_row_band": (C.c_int, [_P(DetectorGeometry), _P(VolumeGeometry), _u32, _u32, _u32, _u32, C.c_int,
                                           _P(RegionOfInterest), _P(_u32), _P(_u32)]),

@@ -84,14 +84,14 @@ class Backend:
         self._ctx = ctx
         self.device = device
         self._owned = set()
-        self._wrapped = []  # weak references to the owners of wrapped volumes
+        self._wrapped = {}  # device address of a wrapped volume -> weak reference to its owner (None: wrapped without one)
 
     # ---- lifetime ------------------------------------------------------------------------------------
     def close(self):
         if self._ctx is not None:
             # projections still deferred into a wrapped (caller-owned) volume: run them while the caller's memory is certainly
             # still there -- paris_hip_ctx_destroy itself only runs pending work into volumes the library allocated
-            if self._wrapped_alive():
+            if self._pending_volume_alive():
                 self._L.paris_hip_flush(self._ctx)
             for p in list(self._owned):
                 self._L.paris_hip_free(self._ctx, C.c_void_p(p))
@@ -99,11 +99,18 @@ class Backend:
             self._L.paris_hip_ctx_destroy(self._ctx)
             self._ctx = None
 
-    def _wrapped_alive(self):
-        for ref in self._wrapped:
-            if ref is None or ref() is None:  # wrapped without an owner / the
-                return False  # owner was collected: that memory may have changed hands, nothing is run into it
-        return True
+    def _pending_volume_alive(self):
+        """True when projections are pending into a wrapped volume whose owner (wrap_volume(owner=...)) is still alive. Decided
+        for THAT volume alone (one owner-less wrap used to switch the close-time flush off for every volume). A
+        volume wrapped without an owner is never flushed into at close: nothing says its memory still belongs to the caller --
+        callers of owner-less wraps call flush() before they let go of the memory."""
+        n, ptr = C.c_uint32(0), C.c_void_p()
+        if self._L.paris_hip_pending_backprojections(self._ctx, C.byref(n), C.byref(ptr)) != 0 or n.value == 0 or not ptr.value:
+            return False
+        for base, (ref, nbytes) in self._wrapped.items():
+            if base <= ptr.value < base + nbytes:
+                return ref is not None and ref() is not None
+        return False
 
     def __enter__(self):
         return self
@@ -163,11 +170,14 @@ class Backend:
         it; clean=False withdraws an earlier promise for the range; clean="scan" lets the device look for -0 once
         (paris_hip_volume_scan_clean) and skip when there is none, under the same duty."""
         v = Volume(ptr, dim_x, dim_y, dim_z, off, on_device=True, owner=owner)
+        import weakref
+        for base in [b for b, (ref, _) in self._wrapped.items() if ref is not None and ref() is None]:
+            del self._wrapped[base]  # owners that have been collected: their wraps are history
         try:
-            import weakref
-            self._wrapped.append(weakref.ref(owner) if owner is not None else None)
+            ref = weakref.ref(owner) if owner is not None else None
         except TypeError:
-            self._wrapped.append(None)
+            ref = None
+        self._wrapped[ptr] = (ref, 4 * dim_x * dim_y * dim_z)
         if clean is True:
             self.volume_mark_clean(v)
         elif clean is False:

@@ -548,6 +548,16 @@ int paris_hip_prevalidate_fast_division(paris_hip_ctx* ctx, float l_px_row, floa
     return fastdiv_is_exact(ctx, l_px_col, &ok);
 }
 
+// the same for the shared-reciprocal form of the two per-column divisions (validate.hip), whose operands d_sd, d_so the detector
+// geometry fixes as well
+int paris_hip_prevalidate_lean_division(paris_hip_ctx* ctx, float d_so, float d_od)
+{
+    if(ctx == nullptr || ctx->bp_lean_div == 0)
+        return PARIS_HIP_SUCCESS;
+    bool ok = false;
+    return paris_hip_lean_division_check(ctx, std::fabs(d_so) + std::fabs(d_od), d_so, &ok);
+}
+
 // Cache policy of the volume stream: 0 plain, 1 nontemporal, 2 nontemporal loads + write-through nontemporal stores. Automatic
 // (ctx->bp_nt < 0): a slab that (mostly) stays in the 256 MiB Infinity Cache between launches must not be pushed out to HBM by
 // nontemporal / write-through accesses -- plain accesses are faster up to about 400 MiB (256^3: 27.3 against 32.8 us per launch,
@@ -607,7 +617,7 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
         const uint64_t ntx = (v_dim_x + 63u) / 64u, nty = (v_dim_y + 3u) / 4u, ntz = (v_dim_z + tz_min - 1u) / tz_min;
         const uint64_t zchunk = chunk_tiles(12u, tz_min, static_cast<uint32_t>(ntz), 64u); // the deepest chunk pads most
         const uint64_t padded = std::max<uint64_t>(8ull * (8u * ((nty + 63u) / 64u)) * ntx * zchunk * ((ntz + zchunk - 1u) / zchunk), // widest deal: groups of 8
-                                                   8ull * ntx * nty * ((ntz + 7u) / 8u));                                             // order 18
+                                                   8ull * ntx * nty * (ntz / 8u) + 8ull * 7u * 8u * ((nty + 63u) / 64u) * ntx);       // order 18: whole rounds + at most 7 shared planes
         if(padded > 0x7fffff00ull)
             return PARIS_HIP_ERROR_UNSUPPORTED;
     }
@@ -660,6 +670,15 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
         const double lo = std::ldexp(1.0, -40), hi = std::ldexp(1.0, 40);
         const bool ordinary = g.d_so >= lo && g.d_so <= hi && g.d_sd >= lo && g.d_sd <= hi;
         g.lean_div = (ctx->bp_lean_div != 0 && ordinary && std::isfinite(reach) && reach <= 0.9 * g.d_so) ? 1u : 0u;
+        if(g.lean_div != 0u)
+        {
+            // ... and the device has compared both lean quotients with the compiler's IEEE divisions for every fp32 denominator of
+            // that range (validate.hip; cached per d_sd, d_so -- paris_hip_stage_filter asks ahead of the first backprojection)
+            bool exact = false;
+            if(int rc = paris_hip_lean_division_check(ctx, g.d_sd, g.d_so, &exact))
+                return rc;
+            g.lean_div = exact ? 1u : 0u;
+        }
     }
     g.p_dim_x_f = static_cast<float>(p_dim_x);
     g.p_dim_y_f = static_cast<float>(p_dim_y);
@@ -678,7 +697,7 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
         g.yfast = tile_nest >= 0 ? static_cast<uint32_t>(tile_nest) : (v_dim_z > 512u ? 2u : 0u);
     }
     // (y tiles fastest is for the fused kernel's box sharing; the volume stream of this kernel loses with it: 2048^3 0.772 -> 0.662, 1024^3 0.743 -> 0.567)
-    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 15u : 18u); // (18 falls back to 5 unless the z tiles divide among the XCDs: settle_order)
+    g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 15u : 18u); // (18 falls back to 5 for volumes of fewer than 8 z tiles: settle_order)
     g.store_sc1 = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) == 2 ? 1u : 0u;
     // 4-pixel staging needs every detector row to start 16-byte (half: 8-byte) aligned
     g.stage_vec4 = (ctx->bp_stage_vec4 != 0 && g.p_pitch % 4u == 0 && reinterpret_cast<uintptr_t>(d_p) % (4u * px) == 0)
@@ -831,6 +850,14 @@ int paris_hip_launch_deferred(paris_hip_ctx* ctx)
         (void)hipGetLastError();
     }
     hipStream_t caller_stream = ctx->stream;
+    if(!overlap && ctx->bp_inflight)
+    {
+        // this group runs on the caller's stream (a single projection, a synchronous ctx, a capture) while earlier groups may still
+        // run on the second one: they add to the same volume and come first
+        PARIS_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->bp_half_done[ctx->bp_last_half], 0));
+        ctx->bp_inflight = false;
+        ctx->bp_half_busy[0] = ctx->bp_half_busy[1] = false;
+    }
     if(overlap)
     {
         if(ctx->bp_stream == nullptr)
@@ -886,6 +913,9 @@ int paris_hip_launch_deferred(paris_hip_ctx* ctx)
             w.active = false;
         if(wrc != PARIS_HIP_SUCCESS)
         {
+            // the group's snapshots are unfiltered and stay so: the group is dropped rather than added to the volume as it is by
+            // the next flush; the caller sees the error
+            ctx->defer_count = 0;
             ctx->stream = caller_stream;
             return wrc;
         }
@@ -961,26 +991,40 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
     const paris_region_of_interest no_roi{};
     const paris_region_of_interest& r = enable_roi ? *roi : no_roi;
     const uint32_t dims[4] = {v_dim_x, v_dim_y, v_dim_z, v_offset};
-    const bool same = ctx->defer_count != 0 && ctx->key_v == d_v && std::memcmp(ctx->key_dims, dims, sizeof(dims)) == 0
+    // the arguments the pending calls share -- or, with nothing pending, those of the group launched last (key_valid): a call that
+    // continues the same reconstruction starts the next group without joining the second stream, so that a whole group's copies
+    // and filters run beside the previous group's fused launch (the join used to come with every group's first call)
+    const bool same = (ctx->defer_count != 0 || ctx->key_valid) && ctx->key_v == d_v && std::memcmp(ctx->key_dims, dims, sizeof(dims)) == 0
                       && std::memcmp(&ctx->key_det, det_geo, sizeof(*det_geo)) == 0 && std::memcmp(&ctx->key_vol, vol_geo, sizeof(*vol_geo)) == 0
                       && ctx->key_enable_roi == (enable_roi ? 1 : 0) && std::memcmp(&ctx->key_roi, &r, sizeof(r)) == 0
                       && std::memcmp(&ctx->key_delta_s, &delta_s, sizeof(float)) == 0 && std::memcmp(&ctx->key_delta_t, &delta_t, sizeof(float)) == 0
-                      && ctx->defer_dim_x == p_dim_x && ctx->defer_dim_y == p_dim_y && ctx->defer_f16 == f16;
+                      && ctx->defer_dim_x == p_dim_x && ctx->defer_dim_y == p_dim_y && ctx->defer_f16 == f16
+                      && ctx->defer_ring != nullptr && ctx->defer_slots >= ctx->defer_depth;
     if(!same)
     {
         if(int rc = paris_hip_flush_deferred(ctx))
             return give_back(rc);
-        if(ctx->defer_dim_x != p_dim_x || ctx->defer_dim_y != p_dim_y || ctx->defer_slots < ctx->defer_depth || ctx->defer_f16 != f16)
+        ctx->key_valid = false;
+        if(ctx->defer_dim_x != p_dim_x || ctx->defer_dim_y != p_dim_y || ctx->defer_slots < ctx->defer_depth || ctx->defer_f16 != f16 || ctx->defer_ring == nullptr)
         {
             if(ctx->defer_ring != nullptr)
             {
-                PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream)); // a launch may still read the old ring
-                PARIS_HIP_TRY(hipFree(ctx->defer_ring));
+                hipError_t err = hipStreamSynchronize(ctx->stream); // a launch may still read the old ring (the flush above joined the second stream)
+                if(err == hipSuccess)
+                    err = hipFree(ctx->defer_ring);
+                if(err != hipSuccess)
+                    return give_back(static_cast<int>(err));
                 ctx->defer_ring = nullptr;
+                ctx->defer_slots = 0;
             }
             ctx->defer_pitch = (static_cast<size_t>(p_dim_x) * px + 255u) / 256u * 256u;
             ctx->defer_f16 = f16;
-            PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->defer_ring), 2u * ctx->defer_pitch * p_dim_y * ctx->defer_depth)); // two halves
+            const hipError_t err = hipMalloc(reinterpret_cast<void**>(&ctx->defer_ring), 2u * ctx->defer_pitch * p_dim_y * ctx->defer_depth); // two halves
+            if(err != hipSuccess)
+            {
+                ctx->defer_ring = nullptr;
+                return give_back(static_cast<int>(err));
+            }
             ctx->defer_dim_x = p_dim_x;
             ctx->defer_dim_y = p_dim_y;
             ctx->defer_slots = ctx->defer_depth;
@@ -993,6 +1037,7 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
         ctx->key_roi = r;
         ctx->key_delta_s = delta_s;
         ctx->key_delta_t = delta_t;
+        ctx->key_valid = true;
         ctx->defer_sin.assign(ctx->defer_depth, 0.f);
         ctx->defer_cos.assign(ctx->defer_depth, 0.f);
         ctx->defer_wf.assign(ctx->defer_depth, paris_hip_ctx::pending_weight_t{});
@@ -1001,17 +1046,23 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
     if(ctx->defer_count == 0 && ctx->bp_half_busy[half])
     {
         // the fused launch that read this half of the ring (two groups ago) must be done before the half is written again
-        PARIS_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->bp_half_done[half], 0));
+        const hipError_t err = hipStreamWaitEvent(ctx->stream, ctx->bp_half_done[half], 0);
+        if(err != hipSuccess)
+            return give_back(static_cast<int>(err));
         ctx->bp_half_busy[half] = false;
     }
     char* slot = reinterpret_cast<char*>(ctx->defer_ring) + ctx->defer_pitch * p_dim_y * (static_cast<size_t>(half) * ctx->defer_slots + ctx->defer_count);
-    if(p_pitch == ctx->defer_pitch) // rows as far apart as the ring's: one linear copy (the padding travels along)
-        PARIS_HIP_TRY(hipMemcpyAsync(slot, d_p, p_pitch * (p_dim_y - 1u) + static_cast<size_t>(p_dim_x) * px, hipMemcpyDeviceToDevice, ctx->stream));
-    else
-        PARIS_HIP_TRY(hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * px, p_dim_y,
-                                       hipMemcpyDeviceToDevice, ctx->stream));
+    {
+        hipError_t err = hipSuccess;
+        if(p_pitch == ctx->defer_pitch) // rows as far apart as the ring's: one linear copy (the padding travels along)
+            err = hipMemcpyAsync(slot, d_p, p_pitch * (p_dim_y - 1u) + static_cast<size_t>(p_dim_x) * px, hipMemcpyDeviceToDevice, ctx->stream);
+        else
+            err = hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * px, p_dim_y, hipMemcpyDeviceToDevice, ctx->stream);
+        if(err != hipSuccess)
+            return give_back(static_cast<int>(err));
+    }
     if(int rc = paris_hip_note_projection_use(ctx, d_p, p_pitch * p_dim_y)) // the snapshot copy is the last reader of the caller's buffer
-        return rc;
+        return give_back(rc);
     ctx->defer_sin[ctx->defer_count] = sin_phi;
     ctx->defer_cos[ctx->defer_count] = cos_phi;
     if(ctx->defer_wf.size() < ctx->defer_depth)
@@ -1044,6 +1095,16 @@ extern "C" int paris_hip_set_backproject_overlap(paris_hip_ctx* ctx, int enable)
     if(int rc = paris_hip_flush_deferred(ctx))
         return rc;
     ctx->bp_overlap = enable ? 1 : 0;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_pending_backprojections(paris_hip_ctx* ctx, uint32_t* count, void** d_v)
+{
+    if(ctx == nullptr || count == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    *count = ctx->defer_count;
+    if(d_v != nullptr)
+        *d_v = ctx->defer_count != 0 ? ctx->key_v : nullptr;
     return PARIS_HIP_SUCCESS;
 }
 

@@ -5,6 +5,7 @@
 #define PARIS_HIP_BP_DEVICE_H_
 
 #include "paris_hip_internal.h"
+#include "ieee_lean.h"
 
 #include <algorithm>
 #include <cmath>
@@ -90,19 +91,12 @@ namespace
         float so_over_den;
         if(g.lean_div)
         {
-            // d_sd / den and d_so / den share their denominator. hipcc expands each IEEE division into v_div_scale x 2, v_rcp, one
-            // Newton step, two quotient corrections, v_div_fmas, v_div_fixup; for operands far from the fp32 range limits (the host
-            // sets lean_div only then, see fill_params) the scalings are by 1 and the fix-up is the identity, so the quotient is
-            //   r = rcp(den) refined once;  q = n r;  q += (n - den q) r;  q += (n - den q) r
-            // bit for bit -- and r serves both numerators: 13 instead of 22 instructions per column.
-            float r = __builtin_amdgcn_rcpf(den);
-            r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.f), r, r);
-            float q1 = g.d_sd * r;
-            q1 = __builtin_fmaf(__builtin_fmaf(-den, q1, g.d_sd), r, q1);
-            c.factor = __builtin_fmaf(__builtin_fmaf(-den, q1, g.d_sd), r, q1);
-            float q2 = g.d_so * r;
-            q2 = __builtin_fmaf(__builtin_fmaf(-den, q2, g.d_so), r, q2);
-            so_over_den = __builtin_fmaf(__builtin_fmaf(-den, q2, g.d_so), r, q2);
+            // d_sd / den and d_so / den share their denominator: one refined reciprocal serves both numerators, 13 instead of 22
+            // instructions per column (ieee_lean.h). The host sets lean_div only after validate.hip has compared both quotients with
+            // the compiler's IEEE divisions for every fp32 denominator this launch can produce (fill_params).
+            const float r = paris_lean::refined_rcp(den);
+            c.factor = paris_lean::div_with_rcp(g.d_sd, den, r);
+            so_over_den = paris_lean::div_with_rcp(g.d_so, den, r);
         }
         else
         {
@@ -151,6 +145,13 @@ namespace
         return grp * ((nty + 8u * grp - 1u) / (8u * grp));
     }
 
+    // order 18, planes left over after the whole rounds of eight: their y tiles are dealt to the XCDs in groups of 8 for the fused
+    // kernel (y tiles of a group fastest: co-resident tiles share their detector boxes) and in pairs for the single-projection one
+    __host__ __device__ inline uint32_t order18_tail_group_log2(const BpParams& g)
+    {
+        return g.yfast == 1u ? 3u : 1u;
+    }
+
     // 1-D grid size for the tile mapping in g.order (tile_of_block rejects the padding blocks)
     // (64-bit: the padded count of a band order can exceed the tile count by the band and chunk rounding; fill_params has checked
     // that the worst case over kernels and orders fits a 1-D grid)
@@ -163,18 +164,19 @@ namespace
             return 8ull * ((g.nty + 7u) / 8u) * g.ntx * g.ntz;
         if(g.order == 12u)
             return 8ull * ((g.nty + 7u) / 8u) * g.ntx * g.zchunk * ((g.ntz + g.zchunk - 1u) / g.zchunk);
-        if(g.order == 18u) // z tiles dealt: 8 XCDs x whole planes x rounds
-            return 8ull * g.ntx * g.nty * ((g.ntz + 7u) / 8u);
+        if(g.order == 18u) // z tiles dealt: 8 XCDs x whole planes x whole rounds, then the planes left over with their y tiles dealt
+            return 8ull * (static_cast<uint64_t>(g.ntx) * g.nty * (g.ntz / 8u)
+                           + static_cast<uint64_t>(g.ntz % 8u) * dealt_band(g.nty, 14u + order18_tail_group_log2(g)) * g.ntx);
         if(g.order >= 14u && g.order <= 17u)
             return 8ull * dealt_band(g.nty, g.order) * g.ntx * g.zchunk * ((g.ntz + g.zchunk - 1u) / g.zchunk);
         return total;
     }
 
-    // Order 18 deals whole planes of tiles to the XCDs, one z tile each in turn: it balances only when the z tiles divide among the
-    // eight (17 z tiles would give one XCD three planes and the others two). Launchers call this after they know their ntz.
+    // Order 18 deals whole planes of tiles to the XCDs, one z tile each in turn; the ntz % 8 planes left over are shared by all XCDs
+    // (tile_of_block). Volumes of fewer than 8 z tiles have nothing to deal: order 5. Launchers call this after they know their ntz.
     inline void settle_order(BpParams& g)
     {
-        if(g.order == 18u && (g.ntz % 8u != 0u))
+        if(g.order == 18u && g.ntz < 8u)
             g.order = 5u;
     }
 
@@ -267,8 +269,41 @@ namespace
             // above / below the cone -- skipped -- all belong to the first and the last XCD, which then finish early. 1024^3, three
             // interleaved rounds on one device: 0.7458 -> 0.7529 of the HBM peak, fused kernel 1799 -> 1825 GVox/s (groups of 2 or
             // 4 z tiles: slower; profiles/r03_ab_zdeal.txt).
+            // A z tile count that does not divide among the eight (natural volumes: 1029 slices = 33 tiles of 32) leaves ntz % 8 planes
+            // over. Dealt as planes they would give some XCDs a plane more than the others (33 tiles: 5 against 4); run by order 5
+            // instead -- rounds 1-3 -- every XCD sweeps a contiguous eighth of the depth and the fused kernel loses 13 % (1024 x 1024 x
+            // 1029 against 1024^3, profiles/r04_ab_order18_tail.txt). So the whole rounds of eight planes are dealt as before and the
+            // planes left over are shared by all XCDs, their y tiles dealt in groups (the dealt orders' mapping, below).
             const uint32_t xcd = b % 8u;
             uint32_t r = b / 8u;
+            const uint32_t full = g.ntz / 8u, plane = g.ntx * g.nty;
+            if(r >= full * plane)
+            {
+                r -= full * plane;
+                const uint32_t lg = order18_tail_group_log2(g), grp = 1u << lg;
+                const uint32_t band = dealt_band(g.nty, 14u + lg);
+                uint32_t yb;
+                if(g.yfast == 1u)
+                {
+                    const uint32_t yl = r % grp;
+                    r /= grp;
+                    bx = r % g.ntx;
+                    r /= g.ntx;
+                    const uint32_t ngrp = band / grp;
+                    yb = (r % ngrp) * grp + yl;
+                    r /= ngrp;
+                }
+                else
+                {
+                    bx = r % g.ntx;
+                    r /= g.ntx;
+                    yb = r % band;
+                    r /= band;
+                }
+                bz = full * 8u + r;
+                by = (yb / grp) * (8u * grp) + xcd * grp + yb % grp;
+                return bz < g.ntz && by < g.nty;
+            }
             if(g.yfast == 1u) // (fused kernel: y fastest, see the dealt orders below)
             {
                 by = r % g.nty;

@@ -222,16 +222,20 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
         (void)hipFree(ctx->colstate);
     for(auto& kv : ctx->proj_pool)
     {
-        (void)hipEventDestroy(kv.second.released);
+        if(kv.second.released != nullptr)
+            (void)hipEventDestroy(kv.second.released);
         (void)hipFree(kv.second.ptr);
     }
     for(auto& kv : ctx->host_pool)
     {
-        (void)hipEventDestroy(kv.second.released);
+        if(kv.second.released != nullptr)
+            (void)hipEventDestroy(kv.second.released);
         (void)hipHostFree(kv.second.ptr);
     }
     for(auto& kv : ctx->upload_targets)
         (void)hipEventDestroy(kv.second.last_use);
+    for(hipEvent_t e : ctx->spare_events)
+        (void)hipEventDestroy(e);
     if(ctx->defer_ring != nullptr)
         (void)hipFree(ctx->defer_ring);
     if(ctx->stage_k != nullptr)
@@ -331,51 +335,94 @@ extern "C" int paris_hip_fence_destroy(paris_hip_ctx* ctx, paris_hip_fence* fenc
 
 // ---- memory ------------------------------------------------------------------------------------------
 
+int paris_hip_take_event(paris_hip_ctx* ctx, hipEvent_t* out)
+{
+    if(!ctx->spare_events.empty())
+    {
+        *out = ctx->spare_events.back();
+        ctx->spare_events.pop_back();
+        return PARIS_HIP_SUCCESS;
+    }
+    PARIS_HIP_TRY(hipEventCreateWithFlags(out, hipEventDisableTiming));
+    return PARIS_HIP_SUCCESS;
+}
+
+void paris_hip_give_event(paris_hip_ctx* ctx, hipEvent_t e)
+{
+    if(e == nullptr)
+        return;
+    if(ctx->spare_events.size() < 256u)
+        ctx->spare_events.push_back(e);
+    else
+        (void)hipEventDestroy(e);
+}
+
+void paris_hip_note_host_use(paris_hip_ctx* ctx, const void* h_ptr, unsigned stream_bit)
+{
+    if(ctx->host_allocs.empty())
+        return;
+    auto a = ctx->host_allocs.upper_bound(const_cast<void*>(h_ptr));
+    if(a == ctx->host_allocs.begin())
+        return;
+    --a;
+    if(static_cast<const char*>(h_ptr) < static_cast<const char*>(a->first) + a->second.bytes)
+        a->second.used |= stream_bit;
+}
+
 namespace
 {
-    // takes the oldest released buffer of `bytes` if it is free to use (or if the pool is full: then waits for it)
-    int pool_take(std::multimap<size_t, paris_hip_ctx::pooled_buffer>& pool, size_t bytes, void** out)
+    using pool_t = std::multimap<size_t, paris_hip_ctx::pooled_buffer>;
+
+    // takes the oldest released buffer of `bytes` if it is free to use (or if that size's share of the pool is full: then waits for it)
+    int pool_take(paris_hip_ctx* ctx, pool_t& pool, size_t bytes, void** out)
     {
         *out = nullptr;
         auto it = pool.lower_bound(bytes);
         if(it == pool.end() || it->first != bytes)
             return PARIS_HIP_SUCCESS;
-        const hipError_t state = hipEventQuery(it->second.released);
-        if(state == hipErrorNotReady)
+        if(it->second.released != nullptr)
         {
-            if(pool.size() < paris_hip_ctx::POOL_MAX)
+            const hipError_t state = hipEventQuery(it->second.released);
+            if(state == hipErrorNotReady)
             {
                 (void)hipGetLastError();
-                return PARIS_HIP_SUCCESS; // let the caller allocate another one; the rotation grows up to POOL_MAX
+                if(pool.count(bytes) < paris_hip_ctx::pool_capacity(bytes))
+                    return PARIS_HIP_SUCCESS; // let the caller allocate another one; the rotation grows up to the capacity
+                PARIS_HIP_TRY(hipEventSynchronize(it->second.released));
             }
-            PARIS_HIP_TRY(hipEventSynchronize(it->second.released));
+            else
+                PARIS_HIP_TRY(state);
+            paris_hip_give_event(ctx, it->second.released);
         }
-        else
-            PARIS_HIP_TRY(state);
-        (void)hipEventDestroy(it->second.released);
         *out = it->second.ptr;
         pool.erase(it);
         return PARIS_HIP_SUCCESS;
     }
 
-    // parks a buffer with an event marking everything enqueued on the ctx streams so far; false when the pool is full
-    int pool_park(paris_hip_ctx* ctx, std::multimap<size_t, paris_hip_ctx::pooled_buffer>& pool, size_t bytes, void* ptr, bool* parked)
+    // parks a buffer behind its last user: an event recorded on `last` now (everything enqueued there so far), or none at all
+    // when nothing used the buffer (last == nullptr and !used); false when that size's share of the pool is full
+    int pool_park(paris_hip_ctx* ctx, pool_t& pool, size_t bytes, void* ptr, bool used, hipStream_t last, bool* parked)
     {
         *parked = false;
-        if(pool.size() >= paris_hip_ctx::POOL_MAX)
+        if(pool.count(bytes) >= paris_hip_ctx::pool_capacity(bytes))
             return PARIS_HIP_SUCCESS;
-        if(ctx->upload_stream != nullptr) // uploads into the buffer happen on the other stream: order the compute stream behind them
-        {
-            hipEvent_t up = nullptr;
-            PARIS_HIP_TRY(hipEventCreateWithFlags(&up, hipEventDisableTiming));
-            PARIS_HIP_TRY(hipEventRecord(up, ctx->upload_stream));
-            PARIS_HIP_TRY(hipStreamWaitEvent(ctx->stream, up, 0));
-            (void)hipEventDestroy(up);
-        }
         hipEvent_t e = nullptr;
-        PARIS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        PARIS_HIP_TRY(hipEventRecord(e, ctx->stream));
-        pool.emplace(bytes, paris_hip_ctx::pooled_buffer{ptr, e});
+        if(used)
+        {
+            if(int rc = paris_hip_take_event(ctx, &e))
+                return rc;
+            const hipError_t err = hipEventRecord(e, last);
+            if(err != hipSuccess)
+            {
+                paris_hip_give_event(ctx, e);
+                return static_cast<int>(err);
+            }
+        }
+        // free-at-once buffers go to the front of their size class (taken first), busy ones behind the older busy ones
+        if(e == nullptr)
+            pool.emplace_hint(pool.lower_bound(bytes), bytes, paris_hip_ctx::pooled_buffer{ptr, e});
+        else
+            pool.emplace(bytes, paris_hip_ctx::pooled_buffer{ptr, e});
         *parked = true;
         return PARIS_HIP_SUCCESS;
     }
@@ -392,11 +439,11 @@ extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, u
     const size_t row = (static_cast<size_t>(dim_x) * sizeof(float) + 255u) & ~static_cast<size_t>(255u);
     const size_t bytes = row * dim_y;
     void* p = nullptr;
-    if(int rc = pool_take(ctx->proj_pool, bytes, &p))
+    if(int rc = pool_take(ctx, ctx->proj_pool, bytes, &p))
         return rc;
     if(p == nullptr)
         PARIS_HIP_TRY(hipMalloc(&p, bytes));
-    ctx->proj_allocs[p] = bytes;
+    ctx->proj_allocs[p] = paris_hip_ctx::proj_alloc{bytes, false};
     *d_ptr = static_cast<float*>(p);
     *pitch = row;
     return PARIS_HIP_SUCCESS;
@@ -598,6 +645,15 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
     auto filt = ctx->filters.find(static_cast<const float*>(d_ptr));
     if(filt != ctx->filters.end())
     {
+        // Filter deferral: slots of the pending group may still hold a weight + filter that reads this K's permuted copy, and the
+        // group filter of a launched group may still run on the second stream: the group runs first, and the compute
+        // stream is ordered behind the second one before the host waits for it
+        bool referenced = ctx->bp_inflight;
+        for(uint32_t i = 0; i < ctx->defer_count && i < ctx->defer_wf.size() && !referenced; ++i)
+            referenced = ctx->defer_wf[i].active && ctx->defer_wf[i].d_kp == filt->second.d_kp;
+        if(referenced)
+            if(int rc = paris_hip_flush_deferred(ctx))
+                return rc;
         PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream)); // a filter launch may still read the permuted copy
         if(filt->second.d_kp != nullptr)
             PARIS_HIP_TRY(hipFree(filt->second.d_kp));
@@ -606,12 +662,14 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
     auto proj = ctx->proj_allocs.find(d_ptr);
     if(proj != ctx->proj_allocs.end())
     {
-        // a projection buffer: deferred backprojections hold their own snapshots, nothing pending refers to it
-        const size_t bytes = proj->second;
+        // a projection buffer: deferred backprojections hold their own snapshots, nothing pending refers to it. Its last user
+        // was enqueued on the compute stream (every upload into it has been followed by a wait of the compute stream for it)
+        const size_t bytes = proj->second.bytes;
+        const bool touched = proj->second.touched;
         ctx->proj_allocs.erase(proj);
         paris_hip_forget_upload_target(ctx, d_ptr);
         bool parked = false;
-        if(int rc = pool_park(ctx, ctx->proj_pool, bytes, d_ptr, &parked))
+        if(int rc = pool_park(ctx, ctx->proj_pool, bytes, d_ptr, touched, ctx->stream, &parked))
             return rc;
         if(parked)
             return PARIS_HIP_SUCCESS;
@@ -660,7 +718,7 @@ void paris_hip_forget_upload_target(paris_hip_ctx* ctx, const void* d_p)
     auto it = ctx->upload_targets.find(d_p);
     if(it != ctx->upload_targets.end())
     {
-        (void)hipEventDestroy(it->second.last_use);
+        paris_hip_give_event(ctx, it->second.last_use);
         ctx->upload_targets.erase(it);
     }
 }
@@ -671,12 +729,12 @@ extern "C" int paris_hip_malloc_host(paris_hip_ctx* ctx, size_t bytes, void** h_
         return rc;
     if(h_ptr == nullptr || bytes == 0)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    if(int rc = pool_take(ctx->host_pool, bytes, h_ptr))
+    if(int rc = pool_take(ctx, ctx->host_pool, bytes, h_ptr))
         return rc;
     if(*h_ptr == nullptr)
         PARIS_HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
     if(bytes <= paris_hip_ctx::POOL_HOST_BYTES)
-        ctx->host_allocs[*h_ptr] = bytes;
+        ctx->host_allocs[*h_ptr] = paris_hip_ctx::host_alloc{bytes, 0u};
     return PARIS_HIP_SUCCESS;
 }
 
@@ -689,10 +747,16 @@ extern "C" int paris_hip_free_host(paris_hip_ctx* ctx, void* h_ptr)
     auto live = ctx->host_allocs.find(h_ptr);
     if(live != ctx->host_allocs.end())
     {
-        const size_t bytes = live->second;
+        const size_t bytes = live->second.bytes;
+        const unsigned used = live->second.used;
         ctx->host_allocs.erase(live);
+        // Copies from / into it may still be in flight; the event goes behind them on the stream that ran them. A frame that went
+        // up through the upload stream alone is released when ITS copy is done, whatever the compute stream still has queued
+        // (the fused launch of the previous group, say). Used from both streams: the compute stream has been made to wait for
+        // every upload (paris_hip_upload_projection), so its tail covers them.
+        hipStream_t last = (used == paris_hip_ctx::USED_UPLOAD && ctx->upload_stream != nullptr) ? ctx->upload_stream : ctx->stream;
         bool parked = false;
-        if(int rc = pool_park(ctx, ctx->host_pool, bytes, h_ptr, &parked)) // copies from it may still be in flight: the event covers them
+        if(int rc = pool_park(ctx, ctx->host_pool, bytes, h_ptr, used != 0u, last, &parked))
             return rc;
         if(parked)
             return PARIS_HIP_SUCCESS;
@@ -715,6 +779,7 @@ extern "C" int paris_hip_memcpy_projection_h2d(paris_hip_ctx* ctx, float* d_dst,
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
                                    hipMemcpyHostToDevice, ctx->stream));
+    paris_hip_note_host_use(ctx, h_src, paris_hip_ctx::USED_COMPUTE);
     if(int rc = paris_hip_note_projection_use(ctx, d_dst, d_pitch * dim_y)) // a later upload into the buffer must not overtake this copy
         return rc;
     return paris_hip_finish(ctx);
@@ -750,11 +815,20 @@ extern "C" int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, siz
     {
         // First upload into this buffer: nothing has been recorded for it yet, but work already queued on the compute stream
         // may read or write it (a frame put there with paris_hip_memcpy_projection_h2d and still being filtered, say) -- the
-        // upload waits for everything queued so far, once per buffer.
+        // upload waits for everything queued so far, once per buffer. Not so for a buffer of paris_hip_malloc_projection that no
+        // library call has touched since it was handed out: the pool gives out only buffers whose last user has finished, so the
+        // transfer starts at once, whatever the compute stream is still busy with (PARIS's loop: a fresh buffer per projection,
+        // src/loader.cpp:28-33).
         paris_hip_ctx::upload_target t;
-        PARIS_HIP_TRY(hipEventCreateWithFlags(&t.last_use, hipEventDisableTiming));
-        PARIS_HIP_TRY(hipEventRecord(t.last_use, ctx->stream));
-        t.used = true;
+        if(int rc = paris_hip_take_event(ctx, &t.last_use))
+            return rc;
+        auto mine = ctx->proj_allocs.find(d_dst);
+        const bool fresh = mine != ctx->proj_allocs.end() && !mine->second.touched;
+        if(!fresh)
+        {
+            PARIS_HIP_TRY(hipEventRecord(t.last_use, ctx->stream));
+            t.used = true;
+        }
         target = ctx->upload_targets.emplace(d_dst, t).first;
     }
     if(target->second.used)
@@ -763,6 +837,8 @@ extern "C" int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, siz
     hipEvent_t done = ctx->upload_events[ctx->uploads++ % ctx->upload_events.size()];
     PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
                                    hipMemcpyHostToDevice, ctx->upload_stream));
+    paris_hip_note_host_use(ctx, h_src, paris_hip_ctx::USED_UPLOAD);
+    paris_hip_mark_touched(ctx, d_dst);
     PARIS_HIP_TRY(hipEventRecord(done, ctx->upload_stream));
     PARIS_HIP_TRY(hipStreamWaitEvent(ctx->stream, done, 0)); // kernels enqueued from now on see the uploaded frame
     return paris_hip_finish(ctx);
@@ -779,6 +855,7 @@ extern "C" int paris_hip_memcpy_projection_d2h(paris_hip_ctx* ctx, float* h_dst,
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     PARIS_HIP_TRY(hipMemcpy2DAsync(h_dst, h_pitch, d_src, d_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
                                    hipMemcpyDeviceToHost, ctx->stream));
+    paris_hip_note_host_use(ctx, h_dst, paris_hip_ctx::USED_COMPUTE);
     if(int rc = paris_hip_note_projection_use(ctx, d_src, d_pitch * dim_y))
         return rc;
     return paris_hip_finish(ctx);
@@ -796,6 +873,7 @@ extern "C" int paris_hip_memcpy_volume_h2d(paris_hip_ctx* ctx, float* d_dst, con
     const size_t bytes = static_cast<size_t>(dim_x) * dim_y * dim_z * sizeof(float);
     volume_written(ctx, d_dst, bytes); // the host's data may hold -0
     PARIS_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    paris_hip_note_host_use(ctx, h_src, paris_hip_ctx::USED_COMPUTE);
     return paris_hip_finish(ctx);
 }
 
@@ -810,6 +888,7 @@ extern "C" int paris_hip_memcpy_volume_d2h(paris_hip_ctx* ctx, float* h_dst, con
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     const size_t bytes = static_cast<size_t>(dim_x) * dim_y * dim_z * sizeof(float);
     PARIS_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    paris_hip_note_host_use(ctx, h_dst, paris_hip_ctx::USED_COMPUTE);
     return paris_hip_finish(ctx);
 }
 

@@ -22,6 +22,7 @@
 //     copy made once per filter, instead of 16 scattered loads per thread;
 //   * optionally the last pass stores IEEE half pixels into a second buffer (BASELINE config 5) instead of fp32 in place.
 #include "paris_hip_internal.h"
+#include "ieee_lean.h"
 
 #include <algorithm>
 #include <cmath>
@@ -54,30 +55,11 @@ namespace
         return v_t * v_t;
     }
 
-    // Correctly rounded sqrt and division as hipcc expands them (v_sqrt_f32 + the +-1 ulp residual test; v_rcp_f32 + one Newton
-    // step + two quotient corrections), minus the parts that only matter at the edges of the fp32 range: the 2^32 pre-scaling
-    // of radicands below 2^-96, the v_div_scale / v_div_fmas rescaling of extreme operands and the special-value fix-ups. For
-    // operands in the safe range those parts are the identity, so the results have the same bits (tests: fused == weight_kernel
-    // bit for bit over the seeded size / geometry fuzz); the host enables this only when d_sd^2 and the largest radicand of the
-    // projection lie in [2^-60, 2^60].
-    __device__ __forceinline__ float sqrt_rn_safe_range(float x)
-    {
-        float s = __builtin_amdgcn_sqrtf(x);
-        const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
-        const float r_lo = __builtin_fmaf(-lo, s, x), r_hi = __builtin_fmaf(-hi, s, x);
-        s = r_lo <= 0.f ? lo : s;
-        s = r_hi > 0.f ? hi : s;
-        return s;
-    }
-
-    __device__ __forceinline__ float div_rn_safe_range(float n, float d)
-    {
-        float r = __builtin_amdgcn_rcpf(d);
-        r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
-        float q = n * r;
-        q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
-        return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
-    }
+    // Correctly rounded sqrt and division as hipcc expands them, minus the parts that only matter at the edges of the fp32 range
+    // (ieee_lean.h). The host enables them (WeightParams::lean) only after validate.hip has compared both with sqrtf and `/` for
+    // every fp32 radicand between d_sd^2 and the largest one of the detector (paris_hip_lean_weighting_check).
+    using paris_lean::div_rn_safe_range;
+    using paris_lean::sqrt_rn_safe_range;
 
     __device__ __forceinline__ float weighted(const WeightParams& w, float px, float dd_hh, float vv)
     {
@@ -631,7 +613,16 @@ int paris_hip_fused_filter_launch(paris_hip_ctx* ctx, float* d_rows, uint32_t pi
         const double dd = static_cast<double>(d_sd) * d_sd;
         const double q_max = dd + std::max(h0 * h0, h1 * h1) + std::max(v0 * v0, v1 * v1);
         const double lo = std::ldexp(1.0, -60), hi = std::ldexp(1.0, 60);
-        a.w.lean = (dd >= lo && q_max <= hi && std::isfinite(q_max) && d_sd > 0.f) ? 1u : 0u;
+        a.w.lean = 0u;
+        if(dd >= lo && q_max <= hi && std::isfinite(q_max) && d_sd > 0.f)
+        {
+            // ... and the device has compared the lean forms with the compiler's sqrtf and `/` for every fp32 radicand of the range
+            // (cached per range: once per detector / row band)
+            bool exact = false;
+            if(int rc = paris_hip_lean_weighting_check(ctx, d_sd, dd, q_max, &exact))
+                return rc;
+            a.w.lean = exact ? 1u : 0u;
+        }
     }
     a.kp = d_kp;
     a.tab_first = plan->d_tab_first;

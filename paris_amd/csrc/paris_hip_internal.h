@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <array>
 #include <cstdint>
 #include <map>
 #include <vector>
@@ -66,6 +67,8 @@ struct paris_hip_ctx
     std::map<uintptr_t, size_t> volume_allocs;
     int bp_lean_div = 1; // share one reciprocal between the two per-column divisions by s + d_so when the operands are in range
     std::map<uint32_t, bool> fastdiv_exact; // divisor bits -> exhaustive check result
+    std::map<std::array<uint32_t, 4>, bool> lean_checks; // (kind, operand bits...) -> device validation result (validate.hip)
+    int lean_validate = 1; // 0: trust the range tests alone (A/B and tests of the validators themselves)
     bool filter_lds_attr_set = false;
     bool filter_r16_attr_set[5] = {false, false, false, false, false}; // LOG2N 10..14
     int filter_variant = 0; // 0: radix-16 register passes for N >= 1024, 1: radix-2 kernel for every N
@@ -116,21 +119,46 @@ struct paris_hip_ctx
     // Projection-sized buffers are recycled instead of returned to the runtime (the reference's CUDA backend pools its device
     // projection buffers too, src/cuda/memory.cpp:42-44): PARIS allocates and frees one host and one device buffer per
     // projection (src/loader.cpp:28-33), and hipMalloc / hipFree / hipHostMalloc cost more than the kernels of a small frame.
-    // A released buffer carries an event recorded on the ctx stream at release time; it is handed out again only after that
-    // event has completed, so the new owner may touch it from the host or from any stream. While the oldest released buffer
-    // is still busy and fewer than POOL_MAX are parked, a fresh one is allocated instead of waiting: an asynchronous caller
-    // ends up rotating through a few buffers and never stalls.
+    // A released buffer carries an event recorded behind its LAST USER, on the stream that ran it: for a pinned host buffer the
+    // H2D copy that read it (the upload stream when the frame went through paris_hip_upload_projection -- nothing queued on the
+    // compute stream holds it back), for a device buffer the compute stream at release time (its last reader -- the filter, the
+    // deferral ring's snapshot copy -- was enqueued there just before). A buffer nothing used is free at once (no event). It is
+    // handed out again only after that event has completed, so the new owner may touch it from the host or from any stream. While
+    // the oldest released buffer is still busy and fewer than pool_capacity(bytes) are parked, a fresh one is allocated instead of
+    // waiting: an asynchronous caller ends up rotating through a few buffers and never stalls.
     struct pooled_buffer
     {
         void* ptr;
-        hipEvent_t released;
+        hipEvent_t released; // nullptr: free at once
     };
-    std::map<void*, size_t> proj_allocs;               // live buffers of paris_hip_malloc_projection -> bytes
-    std::multimap<size_t, pooled_buffer> proj_pool;    // released ones, by size, oldest first (at most POOL_MAX)
-    std::map<void*, size_t> host_allocs;               // live pinned buffers of paris_hip_malloc_host up to POOL_HOST_BYTES -> bytes
+    struct proj_alloc
+    {
+        size_t bytes = 0;
+        bool touched = false; // a library call has read or written it since it was handed out
+    };
+    struct host_alloc
+    {
+        size_t bytes = 0;
+        unsigned used = 0; // streams with copies from / into it since it was handed out (USED_*)
+    };
+    static constexpr unsigned USED_COMPUTE = 1u, USED_UPLOAD = 2u;
+    std::map<void*, proj_alloc> proj_allocs;           // live buffers of paris_hip_malloc_projection
+    std::multimap<size_t, pooled_buffer> proj_pool;    // released ones, by size, oldest first (at most pool_capacity(size) per size)
+    std::map<void*, host_alloc> host_allocs;           // live pinned buffers of paris_hip_malloc_host up to POOL_HOST_BYTES
     std::multimap<size_t, pooled_buffer> host_pool;
-    static constexpr size_t POOL_MAX = 8;
     static constexpr size_t POOL_HOST_BYTES = size_t{64} << 20; // a 4096 x 4096 frame
+    // How far the host may run ahead of the device in buffers of one size: 8 at least, up to 64 MiB worth, 16 at most (a caller
+    // that allocates and frees a buffer per projection blocks in paris_hip_malloc_* once that many are parked and busy). Deep
+    // enough that the device never waits for such a caller -- the rest of a group of deferred projections is supplied while the
+    // previous group's fused launch runs -- and no deeper: a host that is faster than the device grows the rotation to its
+    // capacity in the first milliseconds, and pinning a buffer costs ~0.25 ms per MiB (64 buffers of a 1024^2 frame: 60 ms of a
+    // 500 ms job, measured).
+    static constexpr size_t pool_capacity(size_t bytes)
+    {
+        const size_t by_bytes = bytes ? (size_t{64} << 20) / bytes : 16u;
+        return by_bytes < 8u ? 8u : (by_bytes > 16u ? 16u : by_bytes);
+    }
+    std::vector<hipEvent_t> spare_events; // timing-disabled events ready for reuse (pool releases, upload targets)
     // deferred backprojection (paris_hip_set_backproject_deferral): projections copied at call time into a device ring and
     // added by one fused launch per `defer_depth` calls; the key_* fields are the arguments the pending calls share
     uint32_t defer_depth = 1; // 1 = immediate
@@ -140,6 +168,7 @@ struct paris_hip_ctx
     uint32_t defer_dim_x = 0, defer_dim_y = 0, defer_slots = 0;
     bool defer_f16 = false; // the ring holds IEEE half pixels (calls through paris_hip_backproject_f16)
     float* key_v = nullptr;
+    bool key_valid = false; // the key_* fields describe the group launched last (or pending): a matching call continues it
     uint32_t key_dims[4] = {0, 0, 0, 0}; // v_dim_x, v_dim_y, v_dim_z, v_offset
     paris_detector_geometry key_det{};
     paris_volume_geometry key_vol{};
@@ -181,15 +210,29 @@ inline int paris_hip_finish(paris_hip_ctx* ctx)
     return PARIS_HIP_SUCCESS;
 }
 
+// a pooled projection buffer that contains d_p is no longer "nothing has used it since it was handed out"
+inline void paris_hip_mark_touched(paris_hip_ctx* ctx, const void* d_p)
+{
+    if(ctx->proj_allocs.empty())
+        return;
+    auto a = ctx->proj_allocs.upper_bound(const_cast<void*>(d_p));
+    if(a == ctx->proj_allocs.begin())
+        return;
+    --a;
+    if(static_cast<const char*>(d_p) < static_cast<const char*>(a->first) + a->second.bytes)
+        a->second.touched = true;
+}
+
 // called by every stage entry point after it has enqueued work that reads or writes `bytes` bytes of projection memory
 // starting at d_p (a whole frame, or the rows of a band): every registered upload destination that overlaps the range gets
 // its last-use event re-recorded. Uploads and stage calls may address different row ranges of one frame buffer.
 inline int paris_hip_note_projection_use(paris_hip_ctx* ctx, const void* d_p, size_t bytes)
 {
-    if(ctx->upload_targets.empty())
-        return PARIS_HIP_SUCCESS;
     const char* lo = static_cast<const char*>(d_p);
     const char* hi = lo + (bytes ? bytes : 1u);
+    paris_hip_mark_touched(ctx, d_p);
+    if(ctx->upload_targets.empty())
+        return PARIS_HIP_SUCCESS;
     // Targets may overlap (a driver uploads to interior band pointers that change per task), so ANY earlier-starting target can
     // still reach into the range: all targets that start before hi are tested (a handful of slots per ctx).
     for(auto it = ctx->upload_targets.begin(); it != ctx->upload_targets.end() && static_cast<const char*>(it->first) < hi; ++it)
@@ -203,6 +246,12 @@ inline int paris_hip_note_projection_use(paris_hip_ctx* ctx, const void* d_p, si
 }
 
 void paris_hip_forget_upload_target(paris_hip_ctx* ctx, const void* d_p);
+
+// capi.hip: timing-disabled events, recycled through ctx->spare_events
+int paris_hip_take_event(paris_hip_ctx* ctx, hipEvent_t* out);
+void paris_hip_give_event(paris_hip_ctx* ctx, hipEvent_t e);
+// capi.hip: a copy on `stream_bit`'s stream (paris_hip_ctx::USED_*) reads or writes pinned host memory at h_ptr
+void paris_hip_note_host_use(paris_hip_ctx* ctx, const void* h_ptr, unsigned stream_bit);
 
 inline int paris_hip_bind(paris_hip_ctx* ctx)
 {
@@ -233,8 +282,15 @@ int paris_hip_flush_deferred(paris_hip_ctx* ctx);
 // wait for them -- for the deferring call itself when its ring is full
 int paris_hip_launch_deferred(paris_hip_ctx* ctx);
 
+// validate.hip: device validators of the hand-expanded IEEE sequences of ieee_lean.h, cached per process, device and operand range
+// (*ok = false: the kernels use the compiler's IEEE forms). lean division: both quotients d_sd / den and d_so / den for every fp32
+// den in [0.09, 1.92] x d_so. lean weighting: sqrt and d_sd / sqrt for every fp32 radicand in [dd, q_max] (widened a little).
+int paris_hip_lean_division_check(paris_hip_ctx* ctx, float d_sd, float d_so, bool* ok);
+int paris_hip_lean_weighting_check(paris_hip_ctx* ctx, float d_sd, double dd, double q_max, bool* ok);
+
 // backproject.hip: exhaustive validation of the fast division by the detector's pixel pitches, ahead of the first
 // backprojection (cached per process and device; a no-op once known or when the fast division is switched off)
 int paris_hip_prevalidate_fast_division(paris_hip_ctx* ctx, float l_px_row, float l_px_col);
+int paris_hip_prevalidate_lean_division(paris_hip_ctx* ctx, float d_so, float d_od);
 
 #endif

@@ -124,6 +124,8 @@ extern "C" int paris_hip_stage_filter_rows(paris_hip_ctx* ctx, float* d_p, size_
         // the pixel pitches blocks for ~2 ms on a private stream; paris_hip_backproject then finds it cached and stays asynchronous
         if(int rc = paris_hip_prevalidate_fast_division(ctx, det_geo->l_px_row, det_geo->l_px_col))
             return rc;
+        if(int rc = paris_hip_prevalidate_lean_division(ctx, det_geo->d_so, det_geo->d_od))
+            return rc;
     }
     float* rows = reinterpret_cast<float*>(reinterpret_cast<char*>(d_p) + static_cast<size_t>(row_first) * pitch);
     return paris_hip_apply_filter(ctx, rows, pitch, dim_x, row_count, ctx->stage_k, filter_size, row_count);

@@ -3,8 +3,10 @@
 //
 // usage: paris_hip_demo <n_row> <n_col> <l_px_row> <l_px_col> <delta_s> <delta_t> <d_so> <d_od> <delta_phi>
 //                       <n_proj> <in.raw | lcg> <out.raw> [--no-weight] [--no-filter]
-//                       [--slabs N] [--roi x1 x2 y1 y2 z1 z2] [--vol dx dy dz l_vx]
+//                       [--slabs N] [--roi x1 x2 y1 y2 z1 z2] [--vol dx dy dz l_vx] [--cycle K] [--no-out] [--order N]
 // in.raw holds n_proj frames of n_col x n_row float32; "lcg" generates the SURVEY.md 8c noise frames.
+// --cycle K: only K distinct lcg frames are held in host memory and projection i is frame i mod K (throughput runs over a whole
+// circle of large frames: 1440 frames of 2048^2 would be 23 GiB); --no-out: the volume is neither read back nor written to out.raw.
 // out.raw receives the whole (ROI) volume, slabs written at their slice offsets (fixing SURVEY.md Q4).
 #include <chrono>
 #include <cstdio>
@@ -51,8 +53,10 @@ int main(int argc, char** argv)
         const auto in_path = std::string{argv[11]};
         const auto out_path = std::string{argv[12]};
 
-        bool do_weight = true, do_filter = true, enable_roi = false;
+        bool do_weight = true, do_filter = true, enable_roi = false, write_out = true;
         int slabs = 1;
+        std::uint32_t cycle = 0;
+        int order = -1; // --order N: workgroup -> tile order of the backprojection kernels (A/B; -1 = the library's choice)
         auto roi = paris::region_of_interest{};
         auto vol_geo = paris::calculate_volume_geometry(det);
         for(int a = 13; a < argc; ++a)
@@ -60,6 +64,9 @@ int main(int argc, char** argv)
             if(!std::strcmp(argv[a], "--no-weight")) do_weight = false;
             else if(!std::strcmp(argv[a], "--no-filter")) do_filter = false;
             else if(!std::strcmp(argv[a], "--slabs") && a + 1 < argc) slabs = std::atoi(argv[++a]);
+            else if(!std::strcmp(argv[a], "--cycle") && a + 1 < argc) cycle = static_cast<std::uint32_t>(std::atoi(argv[++a]));
+            else if(!std::strcmp(argv[a], "--no-out")) write_out = false;
+            else if(!std::strcmp(argv[a], "--order") && a + 1 < argc) order = std::atoi(argv[++a]);
             else if(!std::strcmp(argv[a], "--roi") && a + 6 < argc)
             {
                 enable_roi = true;
@@ -88,6 +95,8 @@ int main(int argc, char** argv)
         if(devices.empty())
             throw paris::stage_construction_error{"no HIP device"};
         paris::backend::set_device(devices[0]); // src/main.cpp:87
+        if(order >= 0)
+            paris::backend::detail::runtime_check(paris_hip_set_backproject_order(paris::backend::current_ctx(), order, -1), "--order");
 
         // fixed slab count (the memory-driven count is backend::make_subvolume_information)
         auto info = paris::subvolume_info{};
@@ -97,9 +106,10 @@ int main(int argc, char** argv)
 
         // all frames in host memory (the reference re-reads them per task: src/main.cpp:93)
         const auto frame = std::size_t{det.n_row} * det.n_col;
-        auto frames = std::vector<float>(frame * n_proj);
+        const auto n_held = (in_path == "lcg" && cycle != 0 && cycle < n_proj) ? cycle : n_proj;
+        auto frames = std::vector<float>(frame * n_held);
         if(in_path == "lcg")
-            for(std::uint32_t i = 0; i < n_proj; ++i)
+            for(std::uint32_t i = 0; i < n_held; ++i)
                 lcg_fill(frames.data() + frame * i, frame, i);
         else
         {
@@ -109,10 +119,11 @@ int main(int argc, char** argv)
             std::fclose(f);
         }
 
-        std::FILE* out = std::fopen(out_path.c_str(), "wb");
-        if(out == nullptr)
+        std::FILE* out = write_out ? std::fopen(out_path.c_str(), "wb") : nullptr;
+        if(write_out && out == nullptr)
             throw paris::stage_runtime_error{"cannot open " + out_path};
 
+        double fill_s = 0.0, tail_s = 0.0; // of loop_s: the host's own frame fill (memcpy into the pinned buffer), the wait for the GPU after the last call
         double loop_s = 0.0; // the per-projection loops only (volume allocation, read-back and file output are not the hot path)
         for(int id = 0; id < info.num; ++id) // one task per slab: src/task.cpp:38-48, src/main.cpp:89-108
         {
@@ -123,15 +134,21 @@ int main(int argc, char** argv)
             for(std::uint32_t i = 0; i < n_proj; ++i)
             {
                 auto p = paris::backend::make_projection_host(det.n_row, det.n_col);
-                std::memcpy(p.buf.get(), frames.data() + frame * i, frame * sizeof(float));
+                const auto t_fill = std::chrono::steady_clock::now();
+                std::memcpy(p.buf.get(), frames.data() + frame * (i % n_held), frame * sizeof(float));
+                fill_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fill).count();
                 p.idx = i;
                 auto d_p = paris::load(p);
                 if(do_weight) paris::weight(d_p, det);
                 if(do_filter) paris::filter(d_p, det);
                 paris::backproject(d_p, v, offset, det, vol_geo, false, enable_roi, roi);
             }
+            const auto t_tail = std::chrono::steady_clock::now();
             paris::backend::synchronize(); // the timed region ends when the GPU has finished, not when the last call returned
+            tail_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tail).count();
             loop_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+            if(out == nullptr) // --no-out: a throughput run, the volume is neither read back nor written
+                continue;
             auto h_v = paris::backend::make_volume_host(v.dim_x, v.dim_y, v.dim_z);
             paris::backend::copy_d2h(v, h_v);
             const auto n = std::size_t{v.dim_x} * v.dim_y * v.dim_z;
@@ -139,10 +156,14 @@ int main(int argc, char** argv)
             if(std::fwrite(h_v.buf.get(), sizeof(float), n, out) != n)
                 throw paris::stage_runtime_error{"short write"};
         }
-        std::fclose(out);
+        if(out != nullptr)
+            std::fclose(out);
         std::printf("ok %u %u %u\n", roi_geo.dim_x, roi_geo.dim_y, roi_geo.dim_z);
-        std::printf("projection loops %.3f s: %.1f GVoxel-updates/s through paris::load / weight / filter / backproject (deferral depth %d)\n", loop_s,
-                    static_cast<double>(roi_geo.dim_x) * roi_geo.dim_y * roi_geo.dim_z * n_proj / loop_s / 1e9, PARIS_HIP_BACKPROJECT_DEFERRAL);
+        std::printf("projection loops %.3f s: %.1f GVoxel-updates/s through paris::load / weight / filter / backproject (deferral depth %d, %s)\n", loop_s,
+                    static_cast<double>(roi_geo.dim_x) * roi_geo.dim_y * roi_geo.dim_z * n_proj / loop_s / 1e9, PARIS_HIP_BACKPROJECT_DEFERRAL,
+                    PARIS_HIP_BACKPROJECT_OVERLAP ? "fused launches on the second stream, uploads on the upload stream" : "one stream");
+        std::printf("of which: host frame fill (memcpy into the pinned buffer) %.3f s, backend calls %.3f s, final wait for the GPU %.3f s\n", fill_s,
+                    loop_s - fill_s - tail_s, tail_s);
         return 0;
     }
     catch(const paris::stage_construction_error& e)

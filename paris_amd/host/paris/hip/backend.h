@@ -40,6 +40,13 @@
 #ifndef PARIS_HIP_SYNCHRONOUS_CALLS
 #define PARIS_HIP_SYNCHRONOUS_CALLS 0
 #endif
+// 1 (default): a full group's fused backprojection runs on the ctx's second stream and copy_h2d(projection) on its upload stream, so
+// that the next group's uploads, filters and snapshots -- which PARIS's loop keeps issuing, src/main.cpp:98-105 -- pass the running
+// launch instead of queueing behind it (paris_hip_set_backproject_overlap, paris_hip_upload_projection). The library orders every
+// observer of the volume behind the launches; results are bit-identical. 0: one stream for everything.
+#ifndef PARIS_HIP_BACKPROJECT_OVERLAP
+#define PARIS_HIP_BACKPROJECT_OVERLAP 1
+#endif
 
 #include <cstddef>
 #include <cstdint>
@@ -137,6 +144,7 @@ namespace paris
                 detail::construction_check(paris_hip_set_backproject_deferral(c, PARIS_HIP_BACKPROJECT_DEFERRAL), "set_device()");
                 detail::construction_check(paris_hip_set_stage_fusion(c, PARIS_HIP_STAGE_FUSION), "set_device()");
                 detail::construction_check(paris_hip_set_filter_deferral(c, PARIS_HIP_FILTER_DEFERRAL), "set_device()");
+                detail::construction_check(paris_hip_set_backproject_overlap(c, PARIS_HIP_BACKPROJECT_OVERLAP), "set_device()");
                 it = s.per_device.emplace(d, std::unique_ptr<paris_hip_ctx, detail::ctx_deleter>{c}).first;
             }
             s.current = it->second.get();
@@ -223,8 +231,10 @@ namespace paris
 
         inline auto copy_h2d(const projection_host_type& h_p, projection_device_type& d_p) -> void
         {
-            detail::runtime_check(paris_hip_memcpy_projection_h2d(current_ctx(), d_p.buf.get(), d_p.buf.pitch(), h_p.buf.get(),
-                                                                  std::size_t{h_p.dim_x} * sizeof(float), h_p.dim_x, h_p.dim_y),
+            // on the upload stream when overlapping: the transfer does not wait behind kernels queued on the compute stream, and
+            // the pinned source is released when this copy is done (the compute stream is ordered behind the copy by the library)
+            detail::runtime_check((PARIS_HIP_BACKPROJECT_OVERLAP && !PARIS_HIP_SYNCHRONOUS_CALLS ? paris_hip_upload_projection : paris_hip_memcpy_projection_h2d)(
+                                      current_ctx(), d_p.buf.get(), d_p.buf.pitch(), h_p.buf.get(), std::size_t{h_p.dim_x} * sizeof(float), h_p.dim_x, h_p.dim_y),
                                   "copy_h2d(projection)");
             d_p.idx = h_p.idx; // src/openmp/memory.cpp:60-62
             d_p.phi = h_p.phi;

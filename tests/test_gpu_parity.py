@@ -484,9 +484,9 @@ def test_backproject_every_tile_order_bit_exact(be, oracle, order, tz, dims):
     """Every workgroup -> tile mapping of the tile kernel and of the fused kernel (x / z fastest, a contiguous run per XCD,
     a y band per XCD swept x -> z -> y, x -> y -> z, and in chunks of 256 slices; round 3: y tiles dealt to the XCDs singly, in
     pairs, fours and eights in shallow z chunks, z tiles dealt to the XCDs) covers every voxel exactly once: volumes
-    whose tile counts are not multiples of 8 (the XCD count) or of the deal's group in y, deeper than one chunk, 16 z tiles (what
-    order 18 needs to be used: it falls back to order 5 unless the z tiles divide among the XCDs), with a
-    slab offset; bit-identical to the oracle through single launches and through one fused launch."""
+    whose tile counts are not multiples of 8 (the XCD count) or of the deal's group in y, deeper than one chunk, 16 z tiles (order 18's whole rounds of
+    eight planes), 38, 19 and 15 z tiles (round 4: the planes left over after the whole rounds are shared by all XCDs, y tiles dealt),
+    5 z tiles (fewer than 8: order 18 falls back to order 5), with a slab offset; bit-identical to the oracle through single launches and through one fused launch."""
     g = (96, 80, 0.2, 0.25, -2.5, 1.25, 150, 250, 40.0)
     det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
     nat = B.calculate_volume_geometry(det)
@@ -2044,3 +2044,201 @@ def test_torch_memory_interop(be, oracle, kat_golden):
         out = big.cpu()
     assert_bit_equal(out.numpy(), kat_golden["volume"])
     tb.close()
+
+
+# ---- round 4: the per-projection loop beside the fused launches ------------------------------------------------------
+
+@pytest.mark.parametrize("how", ["free", "rebuild"])
+def test_freeing_the_filter_with_a_deferred_group_pending(oracle, how):
+    """with filter deferral the ring slots of the pending group keep pointers to K's permuted copy until the group
+    launches. Deferral 8 + filter deferral, three projections pending, then K goes away -- paris_hip_free of the K the caller
+    made, or the stage wrapper rebuilding its cached K because the window changed -- and only then is the volume read: the
+    group's filter must have run with the K it was asked for. Equal to the run without filter deferral bit for bit."""
+    g = (512, 24, 0.2, 0.2, 0.75, -0.5, 300, 200, 11.0)
+    det = B.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(80, 72, 20, nat.l_vx_x * 5.0, nat.l_vx_x * 5.0, nat.l_vx_z * 1.1)
+    raws = [oracle.lcg_projection(512, 24, 70 + i) for i in range(3)]
+    fs = B.filter_size(512)
+
+    def run(hold):
+        with B.Backend(0, synchronous=False) as abe:
+            abe.set_stage_fusion(True)
+            abe.set_backproject_deferral(8)
+            abe.set_filter_deferral(hold)
+            abe.set_backproject_overlap(True)
+            d_v = abe.make_volume_device(80, 72, 20)
+            k = abe.make_filter(fs, det.l_px_row) if how == "free" else None
+            for i, raw in enumerate(raws):
+                d_p = to_device(abe, raw, idx=i)
+                B.weight(abe, d_p, det)
+                if how == "free":
+                    abe.apply_filter(d_p, k, fs, det.n_col)
+                else:
+                    B.filter(abe, d_p, det)
+                B.backproject(abe, d_p, d_v, 2, det, vg, False, False, None)
+                abe.free(d_p)
+            if how == "free":
+                abe.free(k)                                   # the pending slots still refer to it
+                junk = [abe.make_filter(fs, 0.37) for _ in range(4)]   # ... and its memory may be handed out again at once
+            else:
+                abe.set_filter_window(1)                      # the next stage filter rebuilds (frees) the cached K
+                d_q = to_device(abe, raws[0], idx=0)
+                B.weight(abe, d_q, det)
+                B.filter(abe, d_q, det)
+                abe.free(d_q)
+            return volume_to_host(abe, d_v)
+
+    want = run(False)
+    got = run(True)
+    assert np.abs(want).max() > 0
+    assert_bit_equal(got, want)
+
+
+def test_close_flushes_only_into_a_wrapped_volume_whose_owner_lives(oracle, kat_golden):
+    """Backend.close() decides per pending volume. Projections deferred into a wrapped tensor that is still alive are
+    run at close, even though ANOTHER volume was wrapped without an owner earlier; projections deferred into an owner-less wrap
+    are not run."""
+    import torch
+    det = B.DetectorGeometry(*KAT)
+    vg = B.calculate_volume_geometry(det)
+    dev = torch.device("cuda", 0)
+    filtered = kat_golden["filtered"]
+
+    def run(owned):
+        vol = torch.zeros((61, 67, 67), dtype=torch.float32, device=dev)
+        other = torch.zeros((4, 8, 8), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        abe = B.Backend(0, synchronous=False)
+        abe.wrap_volume(other.data_ptr(), 8, 8, 4)                       # no owner: must not decide for `vol`
+        v = abe.wrap_volume(vol.data_ptr(), 67, 67, 61, owner=vol if owned else None)
+        abe.set_backproject_deferral(16)
+        pinned = [torch.from_numpy(np.ascontiguousarray(f)).pin_memory() for f in filtered]
+        d_p = abe.make_projection_device(64, 48)
+        for i in range(8):   # (Backend.copy_h2d waits and would flush: the raw asynchronous copy keeps the group pending)
+            assert abe._L.paris_hip_memcpy_projection_h2d(abe._ctx, d_p.ptr, d_p.pitch, pinned[i].data_ptr(), 64 * 4, 64, 48) == 0
+            d_p.idx = i
+            B.backproject(abe, d_p, v, 0, det, vg, False, False, None)
+        n, ptr = C.c_uint32(0), C.c_void_p()
+        assert abe._L.paris_hip_pending_backprojections(abe._ctx, C.byref(n), C.byref(ptr)) == 0
+        assert n.value == 8 and ptr.value == vol.data_ptr()
+        abe.close()
+        torch.cuda.synchronize()
+        return vol.cpu().numpy()
+
+    assert_bit_equal(run(True), kat_golden["volume"])
+    assert not run(False).any()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_per_projection_buffers_through_the_pools_beside_the_fused_launch(oracle, overlap):
+    """PARIS's loop (src/main.cpp:98-105, src/loader.cpp:28-33) over the C ABI: a pinned host buffer and a device buffer are
+    allocated, filled, uploaded (upload stream), weighted, filtered, backprojected (deferral 4) and FREED per projection, nothing
+    synchronising in between; with overlap the fused launches run on the second stream. Released buffers come back from the
+    pools only when their last user has finished: a pinned buffer after its own H2D copy, a device buffer after its snapshot.
+    The host overwrites every pinned buffer it gets at once -- if one came back early the frame in flight would be corrupted.
+    1024 x 64 frames into a 1024 x 1024 x 24 slab (launches long enough to still run when the next buffers are taken), 26
+    projections. Equal bit for bit to the run that synchronises after every call."""
+    n, rows, n_proj = 1024, 64, 26
+    det = B.DetectorGeometry(n, rows, 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 360.0 / n_proj)
+    nat = B.calculate_volume_geometry(det)
+    vg = B.VolumeGeometry(n, n, 24, nat.l_vx_x, nat.l_vx_x, nat.l_vx_z)
+    frames = [oracle.lcg_projection(n, rows, 300 + i) - np.float32(0.5) for i in range(n_proj)]
+
+    def run(synchronise):
+        with B.Backend(0, synchronous=False) as abe:
+            L, ctx = abe._L, abe._ctx
+            abe.set_stage_fusion(True)
+            abe.set_backproject_deferral(4)
+            abe.set_backproject_overlap(overlap)
+            d_v = abe.make_volume_device(n, n, 24)
+            seen_host, seen_dev = set(), set()
+            for i, f in enumerate(frames):
+                h = C.c_void_p()
+                assert L.paris_hip_malloc_host(ctx, n * rows * 4, C.byref(h)) == 0
+                seen_host.add(h.value)
+                C.memmove(h.value, f.ctypes.data, n * rows * 4)          # the host fills the buffer it was just given
+                d_p = abe.make_projection_device(n, rows)
+                seen_dev.add(d_p.ptr)
+                B._lib.check(L.paris_hip_upload_projection(ctx, d_p.ptr, d_p.pitch, h.value, n * 4, n, rows), "upload")
+                d_p.idx = i
+                B.weight(abe, d_p, det)
+                B.filter(abe, d_p, det)
+                B.backproject(abe, d_p, d_v, 0, det, vg, False, False, None)
+                abe.free(d_p)
+                assert L.paris_hip_free_host(ctx, h) == 0
+                if synchronise:
+                    abe.synchronize()
+            vol = volume_to_host(abe, d_v)
+            return vol, len(seen_host), len(seen_dev)
+
+    want, _, _ = run(True)
+    got, n_host, n_dev = run(False)
+    assert np.abs(want).max() > 0
+    assert_bit_equal(got, want)
+    assert n_host < n_proj and n_dev < n_proj                           # buffers did rotate through the pools
+
+
+def test_lean_ieee_sequences_are_validated_on_the_device(be, oracle):
+    """the shared-reciprocal form of the two per-column divisions (bp_device.h) and the short sqrt / divide of
+    the fused weighting (filter_fused.hip) are used only after validate.hip has compared them with the compiler's correctly
+    rounded `/` and sqrtf for EVERY fp32 operand of the launch's range. The checks pass on this toolchain for ordinary
+    geometries (so the kernels do run the short forms), cost well under a millisecond of device time once cached or not, refuse
+    ranges they cannot vouch for, and the volume / weighted frame is the oracle's bit for bit with the validation on and with the
+    rounds 2-3 behaviour (range test alone)."""
+    import time
+    L, ctx = be._L, be._ctx
+    exact = C.c_int(-1)
+    for d_sd, d_so in ((1000.0, 500.0), (300.0, 100.0), (1.0e6, 7.5e5), (3.0e-3, 1.0e-3), (12345.678, 2345.6789)):
+        t0 = time.perf_counter()
+        assert L.paris_hip_lean_division_is_exact(ctx, d_sd, d_so, C.byref(exact)) == 0
+        first = time.perf_counter() - t0
+        assert exact.value == 1, (d_sd, d_so)
+        t0 = time.perf_counter()
+        assert L.paris_hip_lean_division_is_exact(ctx, d_sd, d_so, C.byref(exact)) == 0
+        assert exact.value == 1 and time.perf_counter() - t0 < 1e-3       # cached
+        assert first < 0.25                                                # ~3.7e7 denominators; stream + scratch set-up included
+    # operands the check refuses: a negative or vanishing source distance, a range that reaches the denormals
+    for d_sd, d_so in ((1000.0, -500.0), (1000.0, 0.0), (1.0e-37, 1.0e-38)):
+        assert L.paris_hip_lean_division_is_exact(ctx, d_sd, d_so, C.byref(exact)) == 0
+        assert exact.value == 0
+    for d_sd, q_lo, q_hi in ((1000.0, 1.0e6, 1.09e6), (300.0, 9.0e4, 9.3e4), (0.02, 4.0e-4, 5.0e-4), (5.0e7, 2.5e15, 2.6e15)):
+        assert L.paris_hip_lean_weighting_is_exact(ctx, d_sd, q_lo, q_hi, C.byref(exact)) == 0
+        assert exact.value == 1, (d_sd, q_lo, q_hi)
+    assert L.paris_hip_lean_weighting_is_exact(ctx, 1.0, 1.0e-30, 1.0e30, C.byref(exact)) == 0
+    assert exact.value == 0                                                # 200 binades: not validated, the IEEE forms run
+    assert L.paris_hip_lean_weighting_is_exact(ctx, 1.0, 2.0, 1.0, C.byref(exact)) == 0 and exact.value == 0
+
+    # same bits with the device validation deciding and with the range test alone: weighting + filter of a 512-wide frame ...
+    g = (512, 20, 0.2, 0.25, 1.5, -0.75, 300, 200, 9.0)
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    raw = oracle.lcg_projection(512, 20, 5)
+    outs = []
+    for validate in (1, 0):
+        assert L.paris_hip_set_lean_validation(ctx, validate) == 0
+        d_a, d_b = to_device(be, raw), to_device(be, raw)
+        B.weight_filter_rows(be, d_a, det, 0, 20)                          # one launch: the short sqrt / divide in its load
+        be.set_stage_fusion(False)
+        B.weight(be, d_b, det)                                             # the weighting kernel: plain IEEE operations
+        B.filter(be, d_b, det)
+        a, b = to_host(be, d_a), to_host(be, d_b)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        outs.append(a)
+        be.free(d_a)
+        be.free(d_b)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    # ... and a backprojection against the oracle
+    vg, ovg = B.calculate_volume_geometry(det), oracle.calculate_volume_geometry(odet)
+    frame = oracle.lcg_projection(512, 20, 6) - np.float32(0.5)
+    want = np.zeros((vg.dim_z, vg.dim_y, vg.dim_x), np.float32)
+    sn, cs, ds, dt = oracle.backproject_constants(odet, 3)
+    oracle.backproject(want, frame, 0, odet, ovg, sn, cs, ds, dt)
+    for validate in (1, 0):
+        assert L.paris_hip_set_lean_validation(ctx, validate) == 0
+        d_v = be.make_volume_device(vg.dim_x, vg.dim_y, vg.dim_z)
+        d_p = to_device(be, frame, idx=3)
+        B.backproject(be, d_p, d_v, 0, det, vg, False, False, None)
+        assert_bit_equal(volume_to_host(be, d_v), want)
+        be.free(d_p)
+        be.free(d_v)
+    assert L.paris_hip_set_lean_validation(ctx, 1) == 0
