@@ -45,6 +45,11 @@ extern "C" {
 #define PARIS_HIP_CTX_DEFAULT 0u
 #define PARIS_HIP_CTX_SYNCHRONOUS 1u /* sync the stream before every call returns (reference behaviour) */
 #define PARIS_HIP_CTX_LEGACY_STREAM 2u /* with stream == NULL: enqueue on the legacy default stream instead of a private one */
+/* paris_hip_ctx_create also does the one-off work a per-projection loop would otherwise pay inside its first iterations: the
+ * ctx's upload, second and auxiliary streams and their events are created (a stream costs 2-20 ms), the library's code objects are
+ * loaded and the runtime's host-to-device path is exercised once. What set_device() of the C++ mirror asks for (src/main.cpp:87
+ * binds the device once per thread, before the task loop). Results never depend on it. */
+#define PARIS_HIP_CTX_WARM 4u
 
 /* src/geometry.h:30-46, field for field */
 typedef struct paris_detector_geometry {

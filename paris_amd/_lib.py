@@ -15,6 +15,7 @@ ERROR_UNSUPPORTED = 10003
 CTX_DEFAULT = 0
 CTX_SYNCHRONOUS = 1
 CTX_LEGACY_STREAM = 2
+CTX_WARM = 4
 
 
 class DetectorGeometry(C.Structure):

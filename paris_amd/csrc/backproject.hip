@@ -474,38 +474,20 @@ namespace
     std::mutex fastdiv_mutex;
     std::map<std::pair<int, uint32_t>, bool> fastdiv_cache; // (device, divisor bits) -> exhaustive check result
 
-    int fastdiv_check_on_device(float c, bool* ok)
+    int fastdiv_check_on_device(paris_hip_ctx* ctx, float c, bool* ok)
     {
         *ok = false;
-        hipStream_t s = nullptr;
-        unsigned long long* d_bad = nullptr;
-        unsigned long long* h_bad = nullptr;
-        hipError_t err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-        if(err == hipSuccess)
-            err = hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(*d_bad));
-        if(err == hipSuccess)
-            err = hipHostMalloc(reinterpret_cast<void**>(&h_bad), sizeof(*h_bad), hipHostMallocDefault);
-        if(err == hipSuccess)
-            err = hipMemsetAsync(d_bad, 0, sizeof(*d_bad), s);
-        if(err == hipSuccess)
-        {
-            *h_bad = ~0ull;
-            hipLaunchKernelGGL(fastdiv_validate_kernel, dim3(1u << 16), dim3(256), 0, s, c, 1.f / c, d_bad);
-            err = hipGetLastError();
-        }
-        if(err == hipSuccess)
-            err = hipMemcpyAsync(h_bad, d_bad, sizeof(*h_bad), hipMemcpyDeviceToHost, s);
-        if(err == hipSuccess)
-            err = hipStreamSynchronize(s);
-        if(err == hipSuccess)
-            *ok = *h_bad == 0ull;
-        if(h_bad != nullptr)
-            (void)hipHostFree(h_bad);
-        if(d_bad != nullptr)
-            (void)hipFree(d_bad);
-        if(s != nullptr)
-            (void)hipStreamDestroy(s);
-        return static_cast<int>(err);
+        if(int rc = paris_hip_ensure_aux(ctx))
+            return rc;
+        hipStream_t s = ctx->aux_stream;
+        unsigned long long bad = ~0ull;
+        PARIS_HIP_TRY(hipMemsetAsync(ctx->aux_counter, 0, sizeof(bad), s));
+        hipLaunchKernelGGL(fastdiv_validate_kernel, dim3(1u << 16), dim3(256), 0, s, c, 1.f / c, ctx->aux_counter);
+        PARIS_HIP_TRY(hipGetLastError());
+        PARIS_HIP_TRY(hipMemcpyAsync(&bad, ctx->aux_counter, sizeof(bad), hipMemcpyDeviceToHost, s)); // pageable destination: staged by the runtime
+        PARIS_HIP_TRY(hipStreamSynchronize(s));
+        *ok = bad == 0ull;
+        return PARIS_HIP_SUCCESS;
     }
 
     int fastdiv_is_exact(paris_hip_ctx* ctx, float c, bool* ok)
@@ -525,7 +507,7 @@ namespace
             if(pit == fastdiv_cache.end())
             {
                 bool exact = false;
-                if(int rc = fastdiv_check_on_device(c, &exact))
+                if(int rc = fastdiv_check_on_device(ctx, c, &exact))
                     return rc;
                 pit = fastdiv_cache.emplace(pkey, exact).first;
             }
@@ -860,13 +842,8 @@ int paris_hip_launch_deferred(paris_hip_ctx* ctx)
     }
     if(overlap)
     {
-        if(ctx->bp_stream == nullptr)
-        {
-            PARIS_HIP_TRY(hipStreamCreateWithFlags(&ctx->bp_stream, hipStreamNonBlocking));
-            PARIS_HIP_TRY(hipEventCreateWithFlags(&ctx->bp_ring_ready, hipEventDisableTiming));
-            for(hipEvent_t& e : ctx->bp_half_done)
-                PARIS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
+        if(int rc = paris_hip_ensure_bp_stream(ctx))
+            return rc;
         // everything enqueued on the caller's stream so far -- the snapshots, and whatever touched the volume before them --
         // comes first
         PARIS_HIP_TRY(hipEventRecord(ctx->bp_ring_ready, caller_stream));
@@ -1038,6 +1015,7 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
         ctx->key_delta_s = delta_s;
         ctx->key_delta_t = delta_t;
         ctx->key_valid = true;
+        ctx->defer_ramp = 8u; // a new sequence: its first groups are launched early
         ctx->defer_sin.assign(ctx->defer_depth, 0.f);
         ctx->defer_cos.assign(ctx->defer_depth, 0.f);
         ctx->defer_wf.assign(ctx->defer_depth, paris_hip_ctx::pending_weight_t{});
@@ -1068,8 +1046,9 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
     if(ctx->defer_wf.size() < ctx->defer_depth)
         ctx->defer_wf.resize(ctx->defer_depth);
     ctx->defer_wf[ctx->defer_count] = taken; // (inactive: the snapshot is filtered already)
-    if(++ctx->defer_count == ctx->defer_depth)
+    if(++ctx->defer_count >= std::min(ctx->defer_depth, ctx->defer_ramp))
     {
+        ctx->defer_ramp = ctx->defer_ramp >= ctx->defer_depth ? ctx->defer_depth : ctx->defer_ramp * 2u; // 8, 16, 32 ... then the depth
         if(int rc = paris_hip_launch_deferred(ctx)) // no join: the caller's next calls run beside the launch
             return rc;
         if(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS)
@@ -1096,6 +1075,12 @@ extern "C" int paris_hip_set_backproject_overlap(paris_hip_ctx* ctx, int enable)
         return rc;
     ctx->bp_overlap = enable ? 1 : 0;
     return PARIS_HIP_SUCCESS;
+}
+
+void paris_hip_warm_backproject()
+{
+    hipFuncAttributes a{};
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&fastdiv_validate_kernel));
 }
 
 extern "C" int paris_hip_pending_backprojections(paris_hip_ctx* ctx, uint32_t* count, void** d_v)

@@ -227,3 +227,10 @@ void paris_hip_bp_launch_fused(const void* fused_params, int vx, int tz, bool nt
     else
         launch_fused_flags<4, 16>(fp, nt, fd, stream);
 }
+
+// PARIS_HIP_CTX_WARM: a query of one kernel of this translation unit makes the runtime load its code object now
+void paris_hip_warm_backproject_fused()
+{
+    hipFuncAttributes a{};
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>((&bp_fused_kernel<1, 32, true, true>)));
+}

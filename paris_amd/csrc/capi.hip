@@ -90,7 +90,80 @@ extern "C" int paris_hip_ctx_create(int device, void* stream, unsigned flags, pa
         paris_hip_ctx_destroy(ctx);
         return rc;
     }
+    if(flags & PARIS_HIP_CTX_WARM)
+    {
+        int rc = paris_hip_ensure_aux(ctx);
+        if(rc == PARIS_HIP_SUCCESS)
+            rc = paris_hip_ensure_upload_stream(ctx);
+        if(rc == PARIS_HIP_SUCCESS && !(flags & PARIS_HIP_CTX_SYNCHRONOUS))
+            rc = paris_hip_ensure_bp_stream(ctx);
+        if(rc == PARIS_HIP_SUCCESS)
+        {
+            paris_hip_warm_backproject();
+            paris_hip_warm_backproject_fused();
+            paris_hip_warm_filter();
+            paris_hip_warm_filter_fused();
+            paris_hip_warm_weight();
+            paris_hip_warm_validate();
+            (void)hipGetLastError();
+            // the runtime sets up its staging path on the first blocking host-to-device copy (~9 ms), its DMA queue on the first
+            // asynchronous one from pinned memory (~7 ms): both paid here, on the counter's 8 bytes
+            const unsigned long long zero = 0ull;
+            hipError_t err = hipMemcpy(ctx->aux_counter, &zero, sizeof(zero), hipMemcpyHostToDevice);
+            void* pinned = nullptr;
+            if(err == hipSuccess)
+                err = hipHostMalloc(&pinned, 4096, hipHostMallocDefault);
+            if(err == hipSuccess)
+            {
+                std::memset(pinned, 0, 4096);
+                err = hipMemcpy2DAsync(ctx->aux_counter, sizeof(zero), pinned, sizeof(zero), sizeof(zero), 1, hipMemcpyHostToDevice, ctx->upload_stream);
+                if(err == hipSuccess)
+                    err = hipStreamSynchronize(ctx->upload_stream);
+                (void)hipHostFree(pinned);
+            }
+            rc = static_cast<int>(err);
+        }
+        if(rc != PARIS_HIP_SUCCESS)
+        {
+            paris_hip_ctx_destroy(ctx);
+            return rc;
+        }
+    }
     *out = ctx;
+    return PARIS_HIP_SUCCESS;
+}
+
+int paris_hip_ensure_aux(paris_hip_ctx* ctx)
+{
+    if(ctx->aux_stream == nullptr)
+        PARIS_HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if(ctx->aux_counter == nullptr)
+        PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->aux_counter), sizeof(unsigned long long)));
+    return PARIS_HIP_SUCCESS;
+}
+
+int paris_hip_ensure_upload_stream(paris_hip_ctx* ctx)
+{
+    if(ctx->upload_stream != nullptr)
+        return PARIS_HIP_SUCCESS;
+    PARIS_HIP_TRY(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    for(int i = 0; i < 16; ++i)
+    {
+        hipEvent_t e = nullptr;
+        PARIS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->upload_events.push_back(e);
+    }
+    return PARIS_HIP_SUCCESS;
+}
+
+int paris_hip_ensure_bp_stream(paris_hip_ctx* ctx)
+{
+    if(ctx->bp_stream != nullptr)
+        return PARIS_HIP_SUCCESS;
+    PARIS_HIP_TRY(hipStreamCreateWithFlags(&ctx->bp_stream, hipStreamNonBlocking));
+    PARIS_HIP_TRY(hipEventCreateWithFlags(&ctx->bp_ring_ready, hipEventDisableTiming));
+    for(hipEvent_t& e : ctx->bp_half_done)
+        PARIS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return PARIS_HIP_SUCCESS;
 }
 
@@ -198,12 +271,21 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
     if(ctx->bp_stream != nullptr)
     {
         (void)hipStreamSynchronize(ctx->bp_stream); // fused launches the caller never joined (it never looked at the volume again)
-        (void)hipEventDestroy(ctx->bp_ring_ready);
+        if(ctx->bp_ring_ready != nullptr)
+            (void)hipEventDestroy(ctx->bp_ring_ready);
         for(hipEvent_t e : ctx->bp_half_done)
-            (void)hipEventDestroy(e);
+            if(e != nullptr)
+                (void)hipEventDestroy(e);
         (void)hipStreamDestroy(ctx->bp_stream);
         ctx->bp_stream = nullptr;
     }
+    if(ctx->aux_stream != nullptr)
+    {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+    }
+    if(ctx->aux_counter != nullptr)
+        (void)hipFree(ctx->aux_counter);
     for(auto& kv : ctx->plans)
     {
         (void)hipFree(kv.second.d_twiddle);
@@ -797,16 +879,8 @@ extern "C" int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, siz
     static const bool serial = [] { const char* e = std::getenv("PARIS_HIP_UPLOAD_STREAM"); return e != nullptr && e[0] == '0'; }();
     if(serial) // diagnostic: PARIS_HIP_UPLOAD_STREAM=0 keeps the copy on the compute stream (A/B of the overlap)
         return paris_hip_memcpy_projection_h2d(ctx, d_dst, d_pitch, h_src, h_pitch, dim_x, dim_y);
-    if(ctx->upload_stream == nullptr)
-    {
-        PARIS_HIP_TRY(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
-        for(int i = 0; i < 16; ++i)
-        {
-            hipEvent_t e = nullptr;
-            PARIS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->upload_events.push_back(e);
-        }
-    }
+    if(int rc = paris_hip_ensure_upload_stream(ctx))
+        return rc;
     // Write-after-read on slot reuse: kernels already queued on the compute stream may still read d_dst. The upload waits for
     // the LAST library call that touched this very buffer (paris_hip_note_projection_use records it), not for everything queued:
     // work on other buffers keeps overlapping the transfer. The first upload into a buffer registers it.

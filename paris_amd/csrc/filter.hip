@@ -694,3 +694,10 @@ extern "C" int paris_hip_set_filter_variant(paris_hip_ctx* ctx, int variant)
     ctx->filter_variant = variant;
     return PARIS_HIP_SUCCESS;
 }
+
+// PARIS_HIP_CTX_WARM: a query of one kernel of this translation unit makes the runtime load its code object now
+void paris_hip_warm_filter()
+{
+    hipFuncAttributes a{};
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&make_filter_kernel));
+}

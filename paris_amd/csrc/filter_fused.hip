@@ -642,3 +642,10 @@ int paris_hip_fused_filter_launch(paris_hip_ctx* ctx, float* d_rows, uint32_t pi
         default: return PARIS_HIP_ERROR_UNSUPPORTED;
     }
 }
+
+// PARIS_HIP_CTX_WARM: a query of one kernel of this translation unit makes the runtime load its code object now
+void paris_hip_warm_filter_fused()
+{
+    hipFuncAttributes a{};
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&permute_k_kernel));
+}

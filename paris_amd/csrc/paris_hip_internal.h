@@ -158,11 +158,20 @@ struct paris_hip_ctx
         const size_t by_bytes = bytes ? (size_t{64} << 20) / bytes : 16u;
         return by_bytes < 8u ? 8u : (by_bytes > 16u ? 16u : by_bytes);
     }
+    // validators (backproject.hip: fast division; validate.hip) run on a stream of their own -- never the caller's, which may be
+    // capturing or hold queued work the caller does not want to wait for -- with an 8-byte mismatch counter; made on first use
+    // (or by PARIS_HIP_CTX_WARM) and kept: creating and destroying a stream per check cost more than the checks
+    hipStream_t aux_stream = nullptr;
+    unsigned long long* aux_counter = nullptr;
     std::vector<hipEvent_t> spare_events; // timing-disabled events ready for reuse (pool releases, upload targets)
     // deferred backprojection (paris_hip_set_backproject_deferral): projections copied at call time into a device ring and
     // added by one fused launch per `defer_depth` calls; the key_* fields are the arguments the pending calls share
     uint32_t defer_depth = 1; // 1 = immediate
     uint32_t defer_count = 0; // projections pending in the ring
+    // The first groups of a reconstruction are launched early -- after 8, 16, 32 ... calls, until the depth is reached -- so that
+    // the device starts on the volume while the caller is still feeding the first full group (48 frames of 2048^2 take a host loop
+    // ~60 ms to supply). Reset when a call with other arguments starts a new sequence. Same additions in the same order.
+    uint32_t defer_ramp = 8;
     float* defer_ring = nullptr;
     size_t defer_pitch = 0;
     uint32_t defer_dim_x = 0, defer_dim_y = 0, defer_slots = 0;
@@ -246,6 +255,19 @@ inline int paris_hip_note_projection_use(paris_hip_ctx* ctx, const void* d_p, si
 }
 
 void paris_hip_forget_upload_target(paris_hip_ctx* ctx, const void* d_p);
+
+// capi.hip: the ctx's lazily made pieces (PARIS_HIP_CTX_WARM makes them all at once)
+int paris_hip_ensure_aux(paris_hip_ctx* ctx);           // aux_stream + aux_counter
+int paris_hip_ensure_upload_stream(paris_hip_ctx* ctx); // upload_stream + its event ring
+int paris_hip_ensure_bp_stream(paris_hip_ctx* ctx);     // bp_stream + its events
+// backproject.hip / filter.hip / filter_fused.hip / weight.hip / validate.hip: one cheap query per translation unit that makes the
+// runtime load its code object now rather than at the first launch
+void paris_hip_warm_backproject();
+void paris_hip_warm_backproject_fused();
+void paris_hip_warm_filter();
+void paris_hip_warm_filter_fused();
+void paris_hip_warm_weight();
+void paris_hip_warm_validate();
 
 // capi.hip: timing-disabled events, recycled through ctx->spare_events
 int paris_hip_take_event(paris_hip_ctx* ctx, hipEvent_t* out);

@@ -56,39 +56,26 @@ namespace
     std::mutex lean_mutex;
     std::map<std::pair<int, std::array<uint32_t, 4>>, bool> lean_cache; // (device, key) -> validation result, process-wide
 
-    // Runs one validator launch on a private stream (never the caller's: it may be capturing, or hold queued work the caller does
-    // not want to wait for) and reads the mismatch count back. kind 0: division, 1: weighting.
-    int run_validator(int kind, uint32_t first, uint64_t count, float a, float b, bool* ok)
+    // Runs one validator launch on the ctx's auxiliary stream (never the caller's: it may be capturing, or hold queued work the
+    // caller does not want to wait for) and reads the mismatch count back. kind 0: division, 1: weighting.
+    int run_validator(paris_hip_ctx* ctx, int kind, uint32_t first, uint64_t count, float a, float b, bool* ok)
     {
         *ok = false;
-        hipStream_t s = nullptr;
-        unsigned long long* d_bad = nullptr;
-        unsigned long long h_bad = ~0ull;
-        hipError_t err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-        if(err == hipSuccess)
-            err = hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(*d_bad));
-        if(err == hipSuccess)
-            err = hipMemsetAsync(d_bad, 0, sizeof(*d_bad), s);
-        if(err == hipSuccess)
-        {
-            const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>(4096u, std::max<uint64_t>(1u, (count + 255u) / 256u)));
-            if(kind == 0)
-                hipLaunchKernelGGL(lean_div_validate_kernel, dim3(blocks), dim3(256), 0, s, first, count, a, b, d_bad);
-            else
-                hipLaunchKernelGGL(lean_weight_validate_kernel, dim3(blocks), dim3(256), 0, s, first, count, a, d_bad);
-            err = hipGetLastError();
-        }
-        if(err == hipSuccess)
-            err = hipMemcpyAsync(&h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost, s); // pageable destination: staged by the runtime
-        if(err == hipSuccess)
-            err = hipStreamSynchronize(s);
-        if(err == hipSuccess)
-            *ok = h_bad == 0ull;
-        if(d_bad != nullptr)
-            (void)hipFree(d_bad);
-        if(s != nullptr)
-            (void)hipStreamDestroy(s);
-        return static_cast<int>(err);
+        if(int rc = paris_hip_ensure_aux(ctx))
+            return rc;
+        hipStream_t s = ctx->aux_stream;
+        unsigned long long bad = ~0ull;
+        PARIS_HIP_TRY(hipMemsetAsync(ctx->aux_counter, 0, sizeof(bad), s));
+        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>(4096u, std::max<uint64_t>(1u, (count + 255u) / 256u)));
+        if(kind == 0)
+            hipLaunchKernelGGL(lean_div_validate_kernel, dim3(blocks), dim3(256), 0, s, first, count, a, b, ctx->aux_counter);
+        else
+            hipLaunchKernelGGL(lean_weight_validate_kernel, dim3(blocks), dim3(256), 0, s, first, count, a, ctx->aux_counter);
+        PARIS_HIP_TRY(hipGetLastError());
+        PARIS_HIP_TRY(hipMemcpyAsync(&bad, ctx->aux_counter, sizeof(bad), hipMemcpyDeviceToHost, s)); // pageable destination: staged by the runtime
+        PARIS_HIP_TRY(hipStreamSynchronize(s));
+        *ok = bad == 0ull;
+        return PARIS_HIP_SUCCESS;
     }
 
     uint32_t bits_of(float x)
@@ -112,7 +99,7 @@ namespace
                 bool exact = false;
                 if(int rc = paris_hip_bind(ctx))
                     return rc;
-                if(int rc = run_validator(kind, first, count, a, b, &exact))
+                if(int rc = run_validator(ctx, kind, first, count, a, b, &exact))
                     return rc;
                 pit = lean_cache.emplace(pkey, exact).first;
             }
@@ -210,4 +197,11 @@ extern "C" int paris_hip_set_lean_validation(paris_hip_ctx* ctx, int enable)
     ctx->lean_validate = enable ? 1 : 0;
     ctx->lean_checks.clear();
     return PARIS_HIP_SUCCESS;
+}
+
+// PARIS_HIP_CTX_WARM: a query of one kernel of this translation unit makes the runtime load its code object now
+void paris_hip_warm_validate()
+{
+    hipFuncAttributes a{};
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&lean_div_validate_kernel));
 }

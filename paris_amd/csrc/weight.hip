@@ -122,3 +122,10 @@ extern "C" int paris_hip_set_stage_fusion(paris_hip_ctx* ctx, int enable)
     ctx->stage_fusion = enable ? 1 : 0;
     return PARIS_HIP_SUCCESS;
 }
+
+// PARIS_HIP_CTX_WARM: a query of one kernel of this translation unit makes the runtime load its code object now
+void paris_hip_warm_weight()
+{
+    hipFuncAttributes a{};
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&weight_kernel));
+}

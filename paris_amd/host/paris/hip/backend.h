@@ -135,7 +135,7 @@ namespace paris
             if(it == s.per_device.end())
             {
                 paris_hip_ctx* c = nullptr;
-                detail::construction_check(paris_hip_ctx_create(d, nullptr, PARIS_HIP_SYNCHRONOUS_CALLS ? PARIS_HIP_CTX_SYNCHRONOUS : PARIS_HIP_CTX_DEFAULT, &c),
+                detail::construction_check(paris_hip_ctx_create(d, nullptr, (PARIS_HIP_SYNCHRONOUS_CALLS ? PARIS_HIP_CTX_SYNCHRONOUS : PARIS_HIP_CTX_DEFAULT) | PARIS_HIP_CTX_WARM, &c),
                                            "set_device()");
                 // PARIS calls backproject() once per projection (src/main.cpp:98-105). The library snapshots each call's
                 // projection and adds PARIS_HIP_BACKPROJECT_DEFERRAL of them with one fused launch -- bit-identical, the

@@ -12,6 +12,7 @@ one of an n x n detector and is not read back (--no-out).
 import os
 import subprocess
 import sys
+import time
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n_proj = int(sys.argv[2]) if len(sys.argv) > 2 else 128
@@ -23,7 +24,11 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 print("## n = %d, %d projections (whole job: every projection of the circle through the loop)" % (n, n_proj), flush=True)
 for _ in range(rounds):
     for exe in exes:
+        t0 = time.perf_counter()
         r = subprocess.run([os.path.join(root, "paris_amd", "host", "demo", exe), str(n), str(n), "0.2", "0.2", "0", "0", "500", "500",
                             repr(360.0 / n_proj), str(n_proj), "lcg", "/dev/null", "--cycle", "48", "--no-out"],
                            capture_output=True, text=True)
-        print(exe, "|", " | ".join(r.stdout.strip().splitlines()), r.stderr.strip(), flush=True)
+        wall = time.perf_counter() - t0
+        # (the process also generates its 48 LCG frames, creates the HIP context and -- set_device(), PARIS_HIP_CTX_WARM -- the ctx's
+        # streams and loads the code objects before the loop starts: none of it is in "projection loops")
+        print(exe, "|", " | ".join(r.stdout.strip().splitlines()), r.stderr.strip(), "| whole process %.3f s" % wall, flush=True)
