@@ -410,6 +410,13 @@ def main():
     ap.add_argument("--final-gather", choices=["checksums", "slabs", "off"], default="checksums",
                     help="N > 1, after the timed region and timed separately: the job's one collective. checksums (default): "
                     "all-gather of per-slab checksums; slabs: the slabs themselves gathered on rank 0 (4 GiB each at N = 8)")
+    ap.add_argument("--as-world", type=int, default=0, help="rehearsal of a larger job on fewer processes (the GPU pool allows at "
+                    "most 6 processes on a card, so the 8-rank job cannot run on one GPU at once): the volume is partitioned as for "
+                    "this many ranks and this process takes the slab of rank --as-rank-base + RANK; two runs of 4 processes cover "
+                    "the 8 slabs of BASELINE configs 4 / 5 at their full shape")
+    ap.add_argument("--as-rank-base", type=int, default=0)
+    ap.add_argument("--block-checksums", type=int, default=0, help="N = 1: also report the float64 sum of each of this many z blocks "
+                    "of the volume (the reference's split rule), i.e. the slab checksums an N-rank run of the same projections must reproduce")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line and nothing else: libraries that print there from native code (RCCL's version banner at
@@ -465,8 +472,13 @@ def main():
     det, vol_geo = geometry(B, w)
     roi = B.RegionOfInterest(*w["roi"]) if "roi" in w else None
     out_geo = B.apply_roi(vol_geo, *w["roi"]) if roi is not None else vol_geo  # what is allocated: the ROI (src/main.cpp:124-130)
-    info = sharding.make_subvolume_info(out_geo, world)  # one z-slab per rank
-    z_first, z_count = sharding.slab_of_task(info, rank)
+    vworld = args.as_world if args.as_world > 0 else world  # (rehearsal: the partition of a larger job, --as-world)
+    vrank = args.as_rank_base + rank if args.as_world > 0 else rank
+    if not 0 <= vrank < vworld or (args.as_world > 0 and args.filter_shard):
+        raise SystemExit("bench.py: --as-rank-base %d + rank %d outside the %d-rank partition (or --filter-shard with --as-world)"
+                         % (args.as_rank_base, rank, vworld))
+    info = sharding.make_subvolume_info(out_geo, vworld)  # one z-slab per rank
+    z_first, z_count = sharding.slab_of_task(info, vrank)
 
     # One stream for everything in the step: torch's copies and fills and the library's kernels are ordered on it (a ctx with a
     # private stream would run unordered beside torch's default-stream work). PARIS_BENCH_STREAM picks which stream, for A/B:
@@ -723,7 +735,8 @@ def main():
         torch.cuda.synchronize()
         tg0 = time.perf_counter()
         try:
-            res = sharding.final_gather(dist, vol, info, rank, world, full=(args.final_gather == "slabs"), on_device=on_device)
+            res = sharding.final_gather(dist, vol, info, rank, world, full=(args.final_gather == "slabs"), on_device=on_device,
+                                        task_base=vrank - rank)
             torch.cuda.synchronize()
             barrier()
             tg = max_over_ranks(time.perf_counter() - tg0)
@@ -739,13 +752,23 @@ def main():
 
     voxels_rank = float(z_count) * out_geo.dim_x * out_geo.dim_y
     voxels_all = float(out_geo.dim_z) * out_geo.dim_x * out_geo.dim_y
+    if args.as_world > 0:  # only the slabs of the participating ranks are processed
+        voxels_all = float(sum(sharding.slab_of_task(info, args.as_rank_base + r)[1] for r in range(world))) * out_geo.dim_x * out_geo.dim_y
+    blocks = None
+    if args.block_checksums > 0 and world == 1:
+        binfo = sharding.make_subvolume_info(out_geo, args.block_checksums)
+        torch.cuda.synchronize()
+        blocks = []
+        for t in range(binfo.num):
+            b0, bc = sharding.slab_of_task(binfo, t)
+            blocks.append(float(sharding.slab_checksum(vol[b0:b0 + bc])[0].item()))
 
     # every rank's own kernel statistics, so that a first multi-GPU run explains itself: a slow rank, a rank on another build
     # of the kernel, a rank whose slab reads a wider detector band
     per_rank = None
     if dist is not None:
         ms = kernel_ms or [0.0]
-        mine = {"rank": rank, "device": dev_index, "slab": [z_first, z_count], "detector_row_band": [band_first, band_count],
+        mine = {"rank": rank, "as_rank": vrank, "device": dev_index, "slab": [z_first, z_count], "detector_row_band": [band_first, band_count],
                 "launches": len(kernel_ms), "kernel_ms_min": min(ms), "kernel_ms_mean": sum(ms) / len(ms), "kernel_ms_max": max(ms),
                 "kernel_GVox_per_s": voxels_rank / (sum(ms) / len(ms) * 1e-3) / 1e9 if sum(ms) > 0 else 0.0,
                 "kernel_ms_without_skip": (sum(noskip_ms) / len(noskip_ms)) if noskip_ms else None,
@@ -858,6 +881,12 @@ def main():
                 }
         if gather is not None:
             out["final_gather"] = gather
+        if blocks is not None:
+            out["block_checksums"] = {"blocks": len(blocks), "sums": blocks,
+                                      "what": "float64 sum of every z block of the volume after everything this run added to it"}
+        if args.as_world > 0:
+            out["config"]["as_world"] = vworld
+            out["config"]["as_rank_base"] = args.as_rank_base
         if dist is not None:
             out["config"]["rank_placement"] = placement
             out["config"]["per_rank"] = per_rank

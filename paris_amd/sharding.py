@@ -92,13 +92,14 @@ def slab_checksum(slab):
     return torch.stack([s, q])
 
 
-def final_gather(dist, slab, info, rank, world, full=False, on_device=True, dst=0):
+def final_gather(dist, slab, info, rank, world, full=False, on_device=True, dst=0, task_base=0):
     """The only collective of the job (BASELINE north star: "no RCCL collective needed beyond a final gather"; the
     reference writes each slab from its own thread, src/sink.cpp:72-82). Always: all-gather of the per-slab checksums
     (every rank learns the checksum of checksums). full=True: the slabs themselves are gathered on rank `dst` in task order
     (slabs are padded to the largest slab for the collective; the last one carries the remainder, src/make_volume.cpp:32-34)
     and the assembled volume's checksum is compared with the gathered checksums.
-    on_device: tensors stay on the GPU (nccl = RCCL); otherwise they go through host memory (gloo)."""
+    on_device: tensors stay on the GPU (nccl = RCCL); otherwise they go through host memory (gloo).
+    task_base: rank r holds the slab of task task_base + r (rehearsals of a larger partition on fewer processes)."""
     import torch
     dev = slab.device if on_device else torch.device("cpu")
     mine = slab_checksum(slab).to(dev)
@@ -109,7 +110,7 @@ def final_gather(dist, slab, info, rank, world, full=False, on_device=True, dst=
            "sumsq": [float(v) for v in sums_h[:, 1]]}
     if not full:
         return res
-    counts = [slab_of_task(info, t)[1] for t in range(world)]
+    counts = [slab_of_task(info, task_base + t)[1] for t in range(world)]
     zmax = max(counts)
     plane = slab.shape[1] * slab.shape[2]
     send = slab if on_device else slab.cpu()

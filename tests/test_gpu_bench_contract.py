@@ -179,3 +179,54 @@ def test_config3_line_measures_its_traffic_in_the_run():
     assert d["config"]["whole_job"] is False and rf["launches_timed"] == 4
     fr = d["fused_extension"]["roofline"]
     assert fr["source"].startswith("measured in this run") and 15.0 < fr["valu_instructions_per_voxel_update"] < 40.0
+
+
+def _torchrun(n, extra, timeout=1500):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + extra,
+                       capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return last_json_line(r.stdout)
+
+
+@pytest.mark.parametrize("workload,gather", [("c3", "slabs"), ("c5", "checksums")])
+def test_eight_slab_partition_at_full_shape(workload, gather):
+    """the exact partition of BASELINE configs 4 / 5 -- eight z-slabs of 2048 x 2048 x 256 (config 5: of the
+    2048^3 ROI of the 4096^3 grid, half-precision projections) -- on the one GPU. The pool admits at most six processes on a card
+    (gpurun's process guard), so the eight ranks' work runs as two waves of four gloo ranks (--as-world 8 --as-rank-base 0 / 4):
+    every process is ONE rank of the 8-rank job -- its slab, its slab offset, its detector row band, the full 4 GiB slab in HBM
+    next to the projection stack -- and the job's one collective runs among the four (config 3: the four 4 GiB slabs gathered on
+    rank 0 and re-checksummed). The eight slab checksums must be the float64 sums of the eight 256-slice blocks of an N = 1 run
+    of the same 16 projections (bit-identical slabs sum to identical doubles)."""
+    common = ["--workload", workload, "--steps", "2", "--warmup", "0", "--batch", "8", "--fused-steps", "1", "--cpu-budget", "0",
+              "--cpu-c1", "0", "--noskip-step", "0", "--live-traffic", "0"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--block-checksums", "8"],
+                         capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    want = last_json_line(one.stdout)["block_checksums"]["sums"]
+    assert len(want) == 8 and all(abs(v) > 0 for v in want)
+    got, bands = [], []
+    for base in (0, 4):
+        d = _torchrun(4, common + ["--dist-backend", "gloo", "--device", "0", "--final-gather", gather, "--as-world", "8",
+                                   "--as-rank-base", str(base)])
+        pr = d["config"]["per_rank"]
+        assert [e["as_rank"] for e in pr] == [base + r for r in range(4)]
+        assert [e["slab"] for e in pr] == [[256 * (base + r), 256] for r in range(4)]
+        assert d["config"]["slab_per_gpu"] == [2048, 2048, 256] and d["config"]["as_world"] == 8
+        assert all(e["launches"] == 16 for e in pr)
+        fg = d["final_gather"]
+        assert fg["rccl_ranks_seen"] == 4 and fg["mode"] == gather and len(fg["slab_checksums"]) == 4
+        if gather == "slabs":
+            assert fg["gathered_matches_checksums"] is True and fg["gathered_bytes"] == 3.0 * 4.0 * 2048 * 2048 * 256
+        got += fg["slab_checksums"]
+        bands += [tuple(e["detector_row_band"]) for e in pr]
+    assert got == want
+    # the slabs see different detector bands, higher slabs higher rows, mirrored about the mid-plane; config 3's outermost slabs
+    # reach the detector's first and last row (config 5's ROI is the middle of the grid: its bands stay inside)
+    assert all(bands[t][0] < bands[t + 1][0] for t in range(7)) and all(0 < b[1] < 2048 for b in bands)
+    assert all(bands[t][1] == bands[7 - t][1] and bands[t][0] + bands[t][1] == 2048 - bands[7 - t][0] for t in range(4))
+    if workload == "c3":
+        assert bands[0][0] == 0 and bands[7][0] + bands[7][1] == 2048
