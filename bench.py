@@ -141,6 +141,50 @@ def live_counters(argv_tail, launches=16, fused_batch=16):
     return out
 
 
+def other_workloads(common_tail):
+    """The other BASELINE configs beside the headline: fresh child runs of this script, one at a time, after the
+    headline's measurements are done -- config 1 and 2 as whole jobs, config 4's slab shape (2048 x 2048 x 256, --slices 256) as a
+    whole job, config 5 sampled over the circle (360 of its 3600 launches) -- each reduced to the figures the headline reports for
+    config 3. Children are ordinary child processes of this one (which keeps its GPU context: two processes on the card)."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    plans = [
+        ("c1", ["--workload", "c1", "--steps", "10", "--warmup", "2"]),
+        ("c2", ["--workload", "c2", "--steps", "10", "--warmup", "2"]),
+        ("c4_slab_shape", ["--workload", "c3", "--slices", "256", "--steps", "20", "--warmup", "2"]),
+        ("c5_sampled", ["--workload", "c5", "--steps", "10", "--warmup", "1", "--batch", "36", "--spread", "1"]),
+    ]
+    out = {}
+    for name, argv in plans:
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv + common_tail
+                               + ["--cpu-budget", "0", "--cpu-c1", "0", "--live-traffic", "0", "--workloads", "0"],
+                               cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": (r.stderr or "no JSON line")[-300:]}
+                continue
+            d = json.loads(lines[-1])
+        except (OSError, subprocess.SubprocessError, ValueError) as e:
+            out[name] = {"error": str(e)[:300]}
+            continue
+        rf, cfg = d["roofline"], d["config"]
+        e = {"workload": cfg["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+             "projections_timed": cfg["projections_timed"], "whole_job": cfg["whole_job"], "dtype": d["dtype"],
+             "backproject_kernel_ms": cfg["backproject_kernel_ms"],
+             "roofline": {"bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "unit": rf["unit"],
+                          "frac_without_skip": rf.get("frac_without_skip"), "launches_timed": rf["launches_timed"]},
+             "fused": d.get("fused_extension", {}).get("value"), "fused_kernel_ms_per_launch": d.get("fused_extension", {}).get("kernel_ms_per_launch"),
+             "deferred": d.get("deferred_boundary", {}).get("value"), "wall_seconds_of_the_child_run": time.perf_counter() - t0}
+        if "frac_of_cache_resident_rate" in rf:
+            e["roofline"]["frac_of_cache_resident_rate"] = rf["frac_of_cache_resident_rate"]
+        out[name] = e
+    return out
+
+
 def kernel_source_sha16():
     """fingerprint of the backprojection kernel's sources (as tools/pmc_traffic.py records it)"""
     import hashlib
@@ -410,6 +454,9 @@ def main():
     ap.add_argument("--final-gather", choices=["checksums", "slabs", "off"], default="checksums",
                     help="N > 1, after the timed region and timed separately: the job's one collective. checksums (default): "
                     "all-gather of per-slab checksums; slabs: the slabs themselves gathered on rank 0 (4 GiB each at N = 8)")
+    ap.add_argument("--workloads", type=int, default=1, help="1 (default; N = 1, the whole config-3 job only): after the headline's "
+                    "measurements the other BASELINE configs are run as child processes and summarised under `workloads` "
+                    "(config 1, config 2, config 4's slab shape, config 5 sampled)")
     ap.add_argument("--as-world", type=int, default=0, help="rehearsal of a larger job on fewer processes (the GPU pool allows at "
                     "most 6 processes on a card, so the 8-rank job cannot run on one GPU at once): the volume is partitioned as for "
                     "this many ranks and this process takes the slab of rank --as-rank-base + RANK; two runs of 4 processes cover "
@@ -729,7 +776,9 @@ def main():
 
     # ---- the job's one collective (north star: "no RCCL collective needed beyond a final gather"), timed on its own
     gather = None
-    if dist is not None and world > 1 and args.final_gather != "off":
+    # (N = 1 under torch.distributed.run: only when the slabs are asked for -- it exercises dist.gather and the float64
+    # all_gather_into_tensor on the nccl backend, the two calls a first real multi-GPU run depends on and gloo cannot vouch for)
+    if dist is not None and (world > 1 or args.final_gather == "slabs") and args.final_gather != "off":
         on_device = args.dist_backend == "nccl"
         barrier()
         torch.cuda.synchronize()
@@ -897,6 +946,16 @@ def main():
             out["cpu_baseline"]["cpu_model"] = cpu_model()
             if args.cpu_c1:
                 out["cpu_baseline_c1"] = cpu_baseline_c1()
+        if (args.workloads and world == 1 and dist is None and args.workload == "c3" and args.slices == 0 and args.batch == 0
+                and not under_profiler):
+            # the headline is complete: free its 32 GiB slab and stacks, then the other configs, one child at a time
+            be.free(d_vol)
+            del vol, raw, work
+            torch.cuda.empty_cache()
+            tail = []
+            for name in ("vx", "unroll", "tz", "lds_bytes", "variant", "order", "row_band", "stage_fusion", "fused_batch"):
+                tail += ["--" + name.replace("_", "-"), str(getattr(args, name))]
+            out["workloads"] = other_workloads(tail)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 

@@ -157,6 +157,19 @@ def test_one_rank_under_torchrun_with_rccl_prints_only_the_json_line():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["rank_placement"][0]["rank"] == 0 and "final_gather" not in d
+    # the job's one collective on the nccl (= RCCL) backend, which the gloo rehearsals cannot vouch for --
+    # dist.gather of the slab and all_gather_into_tensor of float64 checksums, at N = 1 (rank 0 gathers its own 64 MiB slab)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload",
+                        "c1", "--steps", "2", "--warmup", "1", "--cpu-budget", "0", "--fused-steps", "0", "--final-gather", "slabs"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    fg = json.loads(lines[0])["final_gather"]
+    assert "error" not in fg, fg
+    assert fg["backend"] == "rccl" and fg["mode"] == "slabs" and fg["rccl_ranks_seen"] == 1
+    assert fg["gathered_matches_checksums"] is True and len(fg["slab_checksums"]) == 1 and fg["slab_checksums"][0] != 0.0
 
 
 def test_config3_line_measures_its_traffic_in_the_run():
@@ -230,3 +243,27 @@ def test_eight_slab_partition_at_full_shape(workload, gather):
     assert all(bands[t][1] == bands[7 - t][1] and bands[t][0] + bands[t][1] == 2048 - bands[7 - t][0] for t in range(4))
     if workload == "c3":
         assert bands[0][0] == 0 and bands[7][0] + bands[7][1] == 2048
+
+
+def test_default_run_reports_every_baseline_config():
+    """the driver's invocation (config 3, whole job, N = 1) ends with a `workloads` object -- config 1 and 2 as
+    whole jobs, config 4's slab shape as a whole job, config 5 sampled over the circle -- each with the headline's figures, from
+    fresh child runs. (CPU legs and the live counter passes are switched off here: they have tests of their own.)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-budget", "0", "--cpu-c1", "0",
+                        "--live-traffic", "0", "--fused-steps", "1", "--noskip-step", "0"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json_line(r.stdout)
+    assert d["config"]["whole_job"] is True and d["config"]["projections_timed"] == 1440
+    wl = d["workloads"]
+    assert sorted(wl) == ["c1", "c2", "c4_slab_shape", "c5_sampled"]
+    for name, e in wl.items():
+        assert "error" not in e, (name, e)
+        for key in ("value", "backproject_kernel_ms", "fused", "deferred", "ms_per_step", "projections_timed", "whole_job"):
+            assert e[key] is not None, (name, key)
+        assert e["value"] > 0 and e["fused"] > e["value"] and 0.3 < e["roofline"]["frac"] < 1.0
+        assert e["roofline"]["frac_without_skip"] is not None
+    assert wl["c1"]["whole_job"] and wl["c2"]["whole_job"] and wl["c4_slab_shape"]["whole_job"] and not wl["c5_sampled"]["whole_job"]
+    assert wl["c1"]["projections_timed"] == 360 and wl["c2"]["projections_timed"] == 720 and wl["c4_slab_shape"]["projections_timed"] == 1440
+    assert wl["c5_sampled"]["projections_timed"] == 360 and wl["c5_sampled"]["dtype"] == "f16-in/f32"
+    assert "frac_of_cache_resident_rate" in wl["c1"]["roofline"]
+    assert "2048, 2048, 256" in str(wl["c4_slab_shape"]["workload"]) or "256 slices" in wl["c4_slab_shape"]["workload"]

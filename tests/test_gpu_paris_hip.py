@@ -170,3 +170,90 @@ def test_missing_geometry_key_fails_like_the_reference(tmp_path):
     r = subprocess.run([EXE, "--geometry", str(geo), "--input", str(tmp_path), "--output", str(tmp_path / "o")],
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "required but missing" in r.stderr
+
+
+def _file_digest(path):
+    """xxh3-128 of a (large) file, read in 64 MiB pieces"""
+    import xxhash
+    h = xxhash.xxh3_128()
+    with open(path, "rb") as f:
+        while True:
+            b = f.read(64 << 20)
+            if not b:
+                break
+            h.update(b)
+    return h.hexdigest(), os.path.getsize(path)
+
+
+def test_eight_device_threads_at_the_config4_partition(tmp_path, oracle):
+    """the driver's 8-device job at full width -- a 2048 x 2048 HIS set (16-bit frames, 16 projections), the
+    natural 2048 x 2048 x 2090 volume, PARIS_HIP_VIRTUAL_DEVICES=8 on the one GPU: the memory planner hands every device one slab
+    (8 slabs of 261 slices, the last one with the remainder: src/cuda/subvolume_information.cpp:112-116), eight feed / device /
+    drain thread triples (src/main.cpp:157-167) reconstruct them side by side in one process and one sink assembles the 35 GB
+    DDBVF file. Byte for byte the file of the one-device run of the same set (which is checked against the oracle on a crop).
+    Falls back to a 2048 x 1024 detector (17 GB file) when the scratch disk is short."""
+    import shutil
+    n_row, n_col = 2048, 2048
+    free = shutil.disk_usage(tmp_path).free  # (one volume file exists at a time: each is digested and removed)
+    if free < 45 * 2 ** 30:
+        n_col = 1024
+    if free < 25 * 2 ** 30:
+        pytest.skip("scratch disk too small for a full-width volume (%.0f GiB free)" % (free / 2 ** 30))
+    n_proj = 16
+    d = tmp_path / "in"
+    d.mkdir()
+    frames = [(oracle.lcg_projection(n_row, n_col, i) * 60000).astype(np.uint16) for i in range(n_proj)]
+    for k in range(2):
+        (d / ("scan_%d.his" % k)).write_bytes(F.his_file_bytes(np.stack(frames[8 * k:8 * k + 8]), 4, 32))
+    g = (n_row, n_col, 0.2, 0.2, 0.0, 0.0, 500, 500, 360.0 / n_proj)
+    geo = tmp_path / "geo.ini"
+    geo.write_text("\n".join("%s = %s" % kv for kv in zip(
+        ("n_row", "n_col", "l_px_row", "l_px_col", "delta_s", "delta_t", "d_so", "d_od", "delta_phi"), g)) + "\n")
+    det = oracle.DetectorGeometry(*g)
+    vg = oracle.calculate_volume_geometry(det)
+
+    def reconstruct(devices, out_dir, slabs):
+        env = dict(os.environ, PARIS_HIP_VIRTUAL_DEVICES=str(devices)) if devices > 1 else dict(os.environ)
+        extra = ["--slabs", str(slabs)] if slabs else []  # (left to itself the driver pipelines several slabs per device)
+        r = subprocess.run([EXE, "--geometry", str(geo), "--input", str(d), "--output", str(out_dir)] + extra, capture_output=True,
+                           text=True, timeout=1500, env=env)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return r.stdout, os.path.join(str(out_dir), "vol.ddbvf")
+
+    out1, f1 = reconstruct(1, tmp_path / "o1", 1)
+    assert "(1 slab)" in out1
+    # the one-device file against the oracle: 12 slices around the mid-plane and 6 at the top of the volume
+    head = F.ddbvf_header_bytes(vg.dim_x, vg.dim_y, vg.dim_z)
+    plane = vg.dim_x * vg.dim_y
+    fs = oracle.filter_size(n_row)
+    k = oracle.make_filter(fs, det.l_px_row)
+    filtered = []
+    for i in range(n_proj):
+        p = frames[i].astype(np.float32)
+        oracle.weight(p, det)
+        oracle.apply_filter(p, k, fs)
+        filtered.append(p)
+    with open(f1, "rb") as fh:
+        assert fh.read(len(head)) == head
+        for z0, cnt in ((vg.dim_z // 2 - 6, 12), (vg.dim_z - 6, 6)):
+            fh.seek(len(head) + 4 * plane * z0)
+            got = np.frombuffer(fh.read(4 * plane * cnt), np.float32).reshape(cnt, vg.dim_y, vg.dim_x)
+            want = np.zeros((cnt, vg.dim_y, vg.dim_x), np.float32)
+            for i in range(n_proj):
+                s, c, ds, dt = oracle.backproject_constants(det, i)
+                oracle.backproject(want, filtered[i], z0, det, vg, s, c, ds, dt)
+            assert np.max(np.abs(got - want)) <= TOL * np.abs(want).max()
+    d1 = _file_digest(f1)
+    os.unlink(f1)
+    assert d1[1] == len(head) + 4 * plane * vg.dim_z
+    # the exact partition of BASELINE config 4 -- one slab per device -- and the driver's own plan (the memory planner sees eight
+    # devices and pipelines several slabs per device: a second volume buffer per device, drained while the next slab is computed)
+    for slabs, tag in ((8, "o8"), (0, "o8p")):
+        out8, f8 = reconstruct(8, tmp_path / tag, slabs)
+        n_slabs = int(out8.split("(")[1].split()[0])
+        assert (n_slabs == 8) if slabs else (n_slabs >= 8 and n_slabs % 8 == 0), out8[:300]
+        lines = [l for l in out8.splitlines() if l.startswith("device ")]
+        assert len(lines) == 8 and sum(int(l.split(":")[1].split()[0]) for l in lines) == n_slabs  # eight device threads share the slab tasks
+        d8 = _file_digest(f8)
+        os.unlink(f8)
+        assert d8 == d1
