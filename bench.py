@@ -792,7 +792,7 @@ def main():
             gather = {"mode": args.final_gather, "seconds": tg, "backend": "rccl" if on_device else args.dist_backend,
                       "rccl_ranks_seen": dist.get_world_size(), "slab_checksums": res["checksums"],
                       "checksum_of_checksums": res["checksum_of_checksums"]}
-            if res.get("gathered_bytes"):
+            if "gathered_bytes" in res:  # (0 bytes cross a link at N = 1: rank 0 gathers its own slab)
                 gather["gathered_bytes"] = res["gathered_bytes"]
                 gather["GBps_into_rank0"] = res["gathered_bytes"] / tg / 1e9
                 gather["gathered_matches_checksums"] = res.get("gathered_matches_checksums")
