@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 run() { echo "== $*" >&2; "$@"; }
 # 1. counters first: bench.py's roofline.traffic and fused_extension.roofline read the newest records under profiles/
 #    (one --pmc pass each, nothing else traced); kernel times for the derived figures come from an unprofiled run
-run python bench.py --steps 8 --warmup 2 --cpu-budget 0 --cpu-c1 0 --live-traffic 0 > $out/quick.json
+run python bench.py --steps 8 --warmup 2 --cpu-budget 0 --cpu-c1 0 --live-traffic 0 --workloads 0 > $out/quick.json
 A="--steps 1 --warmup 1 --batch 16 --spread 1 --cpu-budget 0 --cpu-c1 0 --noskip-step 0 --live-traffic 0"  # 16 timed launches that sample the whole circle
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/prof_fetch -- python3 bench.py $A > /dev/null
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/prof_write -- python3 bench.py $A > /dev/null
@@ -23,8 +23,8 @@ run rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYC
 run rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_sq_b -- python3 bench.py $S > /dev/null
 python tools/pmc_sq.py $out/pmc_sq_a $out/pmc_sq_b $out/quick.json $out/${tag}_pmc_sq_counters_c3.json "$S"
 run rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_w1 -- python3 bench.py $S > /dev/null
-python tools/pmc_wait.py $out/pmc_w1 $out/pmc_sq_a > $out/${tag}_pmc_wave_states_c3.json
-cp $out/${tag}_pmc_traffic_c3.json $out/${tag}_pmc_sq_counters_c3.json profiles/
+python tools/pmc_wait.py $out/pmc_w1 $out/pmc_sq_a $out/quick.json > $out/${tag}_pmc_wave_states_c3.json
+cp $out/${tag}_pmc_traffic_c3.json $out/${tag}_pmc_sq_counters_c3.json $out/${tag}_pmc_wave_states_c3.json profiles/
 echo "counters done" >&2
 # 2. the bench lines
 run python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_c3.json

@@ -28,7 +28,8 @@ def collect(d):
 
 def main():
     a_dir, b_dir, bench_json, out_path, args = sys.argv[1:6]
-    bench = json.load(open(bench_json))
+    with open(bench_json) as f:
+        bench = json.loads([l for l in f if l.startswith("{")][-1])
     a, b = collect(a_dir), collect(b_dir)
     voxels = 1.0
     for v in bench["config"]["slab_per_gpu"]:
@@ -51,7 +52,16 @@ def main():
             "derived": {
                 "valu_instructions_per_voxel_update": c["SQ_INSTS_VALU"] * 64.0 / updates if "SQ_INSTS_VALU" in c else None,
                 "lds_instructions_per_voxel_update": c["SQ_INSTS_LDS"] * 64.0 / updates if "SQ_INSTS_LDS" in c else None,
-                "valu_issue_utilisation (SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles / 4), 2.4 GHz)":
+                # A wave64 VALU instruction occupies its SIMD-32's issue port for 2 cycles (MI355X_MICROARCH.md: "issues each VALU
+                # instruction over 2 cycles"): issue-port cycles used / cycles available at the nominal 2.4 GHz. (Round 3 divided
+                # SQ_ACTIVE_INST_VALU -- quad-cycles summed over WAVES, several of which are in flight per SIMD -- by the SIMDs'
+                # quad-cycles and got 1.35 for the fused kernel: not a utilisation.)
+                "valu_issue_utilisation (SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles), 2.4 GHz)":
+                    c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles) if "SQ_INSTS_VALU" in c else None,
+                "valu_lane_instructions_per_second_T": c["SQ_INSTS_VALU"] * 64.0 / (ms * 1e-3) / 1e12 if "SQ_INSTS_VALU" in c else None,
+                "fraction_of_measured_v_mul_f32_issue_rate (58.12 T lane-instr/s, profiles/r01_pkbench.txt)":
+                    c["SQ_INSTS_VALU"] * 64.0 / (ms * 1e-3) / 58.12e12 if "SQ_INSTS_VALU" in c else None,
+                "valu_active_wave_quad_cycles_per_simd_quad_cycle (SQ_ACTIVE_INST_VALU / (1024 x kernel cycles / 4); summed over waves, may exceed 1)":
                     c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles / 4.0) if "SQ_ACTIVE_INST_VALU" in c else None,
                 "lds_busy_fraction (SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles))":
                     c["SQ_LDS_IDX_ACTIVE"] / (256.0 * cycles) if "SQ_LDS_IDX_ACTIVE" in c else None,
