@@ -885,7 +885,7 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
                 # achieved is priced on the ALGORITHMIC bytes (8 B for every voxel-update the reference performs); measured traffic
                 # below them = tiles no ray of the projection reaches, which the library leaves untouched (the reference adds +0
-                # there; bit-identical for a library-allocated volume: paris_hip_set_backproject_skip_invalid)
+                # there; bit-identical for a library-allocated volume: paris_hip_set_backproject_skip_invalid, DESIGN.md 4.1, profiles/HISTORY.md)
                 "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
                 # the DRAM-side fraction: measured bytes (tiles no ray reaches are not moved) over this run's kernel time
                 "frac_dram": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,

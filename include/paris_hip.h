@@ -331,8 +331,13 @@ int paris_hip_set_filter_deferral(paris_hip_ctx* ctx, int enable);
  * the ctx stream -- execute beside it instead of behind it (what small volumes need: a 256^3 launch of 16 projections takes about
  * as long as the sixteen copy + filter launches of the next group). Every entry point that flushes (see above) also makes the ctx
  * stream wait for the launches on the second stream, so the caller sees one stream's worth of ordering. Not used under
- * PARIS_HIP_CTX_SYNCHRONOUS or while the ctx stream is being captured into a graph. Results never depend on it. Off by default: on
- * MI355X the fused kernel leaves the other stream's small kernels no room and the switch measured slower. */
+ * PARIS_HIP_CTX_SYNCHRONOUS or while the ctx stream is being captured into a graph. Results never depend on it. Off by default in
+ * the bare library; the C++ mirror paris::hip switches it on (macro PARIS_HIP_BACKPROJECT_OVERLAP): PARIS's loop uploads, filters and
+ * snapshots the next group while a launch runs, and without the second stream all of that -- and the release of every buffer of
+ * the loop -- queues behind the launch: whole circles through the mirror 1.65 -> 1.97 TVox/s at 2048^2, 1.30 -> 1.90 at 1024^2,
+ * 0.88 -> 1.78 at 512^2 (profiles/r04_demo_paris_hip_mirror.txt; a call with the same arguments as the group launched last
+ * continues without joining the streams -- until round 4 every group's first call joined, and nothing overlapped). With the
+ * projections already resident on the device there is nothing to pass and the switch changes nothing (bench.py --overlap). */
 int paris_hip_set_backproject_overlap(paris_hip_ctx* ctx, int enable);
 
 /* ---- stage wrappers and geometry (host code of the hot path) ----------------------------------------

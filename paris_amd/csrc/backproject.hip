@@ -6,7 +6,7 @@
 // Numerics: every fp32 operation is the reference's, in the reference's order, rounded once (IEEE divide,
 // no FMA contraction), so the volume is bit-identical to the OpenMP backend's.
 //
-// Mapping (DESIGN.md "Backprojection kernel"):
+// Mapping (the measurements behind it: profiles/HISTORY.md 4.1):
 //   - a 256-thread workgroup owns a tile of 64 (x) x TY (y) voxel columns and walks TZ slices in z;
 //   - lanes of a wave cover x contiguously (VX voxels per lane, 16 B / 8 B / 4 B accesses), so every
 //     volume load/store instruction touches whole 256-byte runs of the x-fastest volume;

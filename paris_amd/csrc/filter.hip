@@ -7,7 +7,7 @@
 // straight into LDS, transforms, scales and inverse-transforms them there, and writes the first dim_x samples
 // back: 8 B of HBM traffic per pixel.
 //
-// Algorithm (DESIGN.md "Filter kernel"):
+// Algorithm (profiles/HISTORY.md 4.2):
 //   - two real rows a, b are packed as z = a + i b. The filter is a real, even multiplier K, so
 //     IFFT(K * FFT(z)) = filt(a) + i filt(b): no split/merge of the spectra is needed;
 //   - forward transform = radix-2 decimation in frequency (natural order in, bit-reversed order out),

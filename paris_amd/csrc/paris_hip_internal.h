@@ -187,13 +187,14 @@ struct paris_hip_ctx
     std::vector<float> defer_sin, defer_cos;
     // The fused launch of a full ring runs on a stream of its own (bp_stream), ordered behind the group's snapshot copies by an
     // event, so that the copies / weightings / filters of the NEXT group, which the caller keeps enqueuing on `stream`, run
-    // beside it instead of behind it (small volumes: a 256^3 launch of 16 projections takes 235 us, the sixteen copy + filter
-    // launches of the next group 190 us). MEASURED: it does not pay -- the fused kernel fills every SIMD's register file, the small
-    // kernels of the other stream get no slots until its workgroups drain, and the cross-stream events cost more than they hide:
-    // config 1 through deferred calls 645 -> 550 GVox/s, nothing to gain at configs 2-5 (profiles/r03_ab_overlap_c1.txt). Off by
-    // default, kept as a knob. The ring has two halves, written alternately; a half is written again only after the
-    // launch that read it has finished (bp_half_done). Every entry point that observes a volume or completes work joins:
-    // `stream` is made to wait for the last fused launch (paris_hip_flush_deferred).
+    // beside it instead of behind it. Round 3 measured a loss and kept it off -- but its first call of every group still joined
+    // the streams, so nothing overlapped; since round 4 a call that continues the reconstruction of the group launched
+    // last (key_valid) starts the next group without a join, and PARIS's per-projection loop through paris::hip -- whose uploads,
+    // filters, snapshots and buffer releases otherwise queue behind the running launch -- gains 19 ... 100 %
+    // (profiles/r04_demo_paris_hip_mirror.txt). Off by default in the bare library, on in paris::hip. The ring has two halves,
+    // written alternately; a half is written again only after the launch that read it has finished (bp_half_done). Every entry
+    // point that observes a volume or completes work joins: `stream` is made to wait for the last fused launch
+    // (paris_hip_flush_deferred); a group that runs on `stream` itself (a single projection, a synchronous ctx) joins first.
     int bp_overlap = 0;               // knob (paris_hip_set_backproject_overlap), off by default; ignored under PARIS_HIP_CTX_SYNCHRONOUS
     hipStream_t bp_stream = nullptr;
     hipEvent_t bp_ring_ready = nullptr;            // recorded on `stream`: the group's snapshots are in the ring
