@@ -885,32 +885,41 @@ extern "C" int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, siz
     // the LAST library call that touched this very buffer (paris_hip_note_projection_use records it), not for everything queued:
     // work on other buffers keeps overlapping the transfer. The first upload into a buffer registers it.
     auto target = ctx->upload_targets.find(d_dst);
+    bool fresh = false;
     if(target == ctx->upload_targets.end())
     {
         // First upload into this buffer: nothing has been recorded for it yet, but work already queued on the compute stream
         // may read or write it (a frame put there with paris_hip_memcpy_projection_h2d and still being filtered, say) -- the
         // upload waits for everything queued so far, once per buffer. Not so for a buffer of paris_hip_malloc_projection that no
         // library call has touched since it was handed out: the pool gives out only buffers whose last user has finished, so the
-        // transfer starts at once, whatever the compute stream is still busy with (PARIS's loop: a fresh buffer per projection,
-        // src/loader.cpp:28-33).
-        paris_hip_ctx::upload_target t;
-        if(int rc = paris_hip_take_event(ctx, &t.last_use))
-            return rc;
+        // transfer starts at once, whatever the compute stream is still busy with, and the buffer is not even registered --
+        // PARIS's loop takes a fresh buffer per projection and frees it after one use (src/loader.cpp:28-33); should the caller
+        // upload into it a second time after all, that upload finds it touched and unregistered and takes the conservative path.
         auto mine = ctx->proj_allocs.find(d_dst);
-        const bool fresh = mine != ctx->proj_allocs.end() && !mine->second.touched;
+        fresh = mine != ctx->proj_allocs.end() && !mine->second.touched;
         if(!fresh)
         {
+            paris_hip_ctx::upload_target t;
+            if(int rc = paris_hip_take_event(ctx, &t.last_use))
+                return rc;
             PARIS_HIP_TRY(hipEventRecord(t.last_use, ctx->stream));
             t.used = true;
+            target = ctx->upload_targets.emplace(d_dst, t).first;
         }
-        target = ctx->upload_targets.emplace(d_dst, t).first;
     }
-    if(target->second.used)
-        PARIS_HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, target->second.last_use, 0));
-    target->second.bytes = std::max(target->second.bytes, d_pitch * dim_y);
+    if(!fresh)
+    {
+        if(target->second.used)
+            PARIS_HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, target->second.last_use, 0));
+        target->second.bytes = std::max(target->second.bytes, d_pitch * dim_y);
+    }
     hipEvent_t done = ctx->upload_events[ctx->uploads++ % ctx->upload_events.size()];
-    PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
-                                   hipMemcpyHostToDevice, ctx->upload_stream));
+    // rows as far apart on both sides as they are long: one linear copy (the 2-D form costs the runtime more per call)
+    if(d_pitch == h_pitch && d_pitch == static_cast<size_t>(dim_x) * sizeof(float))
+        PARIS_HIP_TRY(hipMemcpyAsync(d_dst, h_src, d_pitch * dim_y, hipMemcpyHostToDevice, ctx->upload_stream));
+    else
+        PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
+                                       hipMemcpyHostToDevice, ctx->upload_stream));
     paris_hip_note_host_use(ctx, h_src, paris_hip_ctx::USED_UPLOAD);
     paris_hip_mark_touched(ctx, d_dst);
     PARIS_HIP_TRY(hipEventRecord(done, ctx->upload_stream));

@@ -38,5 +38,19 @@ echo "benches done" >&2
 run rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 5 --cpu-budget 0 --cpu-c1 0 --live-traffic 0 > $out/${tag}_bench_under_rocprof_c3.json
 cp $(ls $out/stats/*/*_kernel_stats.csv | head -1) $out/${tag}_kernel_stats_bench_c3_whole_job.csv
 echo "kernel stats done" >&2
-rm -rf $out/stats $out/prof_fetch $out/prof_write $out/pmc_sq_a $out/pmc_sq_b $out/pmc_w1 $out/quick.json
+# 4. PARIS's own per-projection loop through the C++ mirror paris::hip, whole circles (tools/demo_bench.py), and the device timeline
+#    of one such job (are the fused launches back to back?)
+{
+  python tools/demo_bench.py 512 360 2 demo,serial,immediate
+  python tools/demo_bench.py 512 1536 2 demo,serial,immediate
+  python tools/demo_bench.py 1024 720 2 demo,serial,immediate
+  python tools/demo_bench.py 2048 1440 1 demo,serial
+  python tools/demo_bench.py 2048 240 1 immediate
+  echo "## BASELINE config 1 itself (256^3 volume from 512^2 projections, 360 of them): the loop is bound by its own host work per projection"
+  for i in 1 2; do paris_amd/host/demo/paris_hip_demo 512 512 0.2 0.2 0 0 500 500 1.0 360 lcg /dev/null --cycle 48 --no-out --vol 256 256 256 0.19973 | tr "\n" " "; echo; done
+} > $out/${tag}_demo_paris_hip_mirror.txt 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OLDPWD/$out/demo_trace -- $OLDPWD/paris_amd/host/demo/paris_hip_demo 1024 1024 0.2 0.2 0 0 500 500 0.5 720 lcg /dev/null --cycle 48 --no-out > /dev/null 2>&1 )
+{ echo "# rocprofv3 --kernel-trace --memory-copy-trace -- paris_hip_demo 1024 1024 ... 720 lcg (PARIS's loop through paris::hip, whole circle): tools/timeline.py"; python tools/timeline.py $out/demo_trace; } > $out/${tag}_demo_timeline_1024.txt 2>&1
+echo "demo done" >&2
+rm -rf $out/demo_trace $out/stats $out/prof_fetch $out/prof_write $out/pmc_sq_a $out/pmc_sq_b $out/pmc_w1 $out/quick.json
 ls -la $out >&2
