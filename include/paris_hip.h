@@ -125,7 +125,12 @@ int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim
 /* device volume, zero-filled (make_volume_device semantics: src/openmp/memory.cpp:46-47) */
 int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, float** d_ptr);
 int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr);
-/* pinned host memory for projection/volume host buffers (cuda: pinned_host_ptr) */
+/* pinned host memory for projection/volume host buffers (cuda: pinned_host_ptr).
+ * Projection-sized buffers (host ones up to 64 MiB) are recycled: paris_hip_free / paris_hip_free_host return at once, and the
+ * buffer is handed out again only after the work of THIS API that used it has finished -- a pinned buffer after the last copy from /
+ * into it (an upload-stream copy does not wait for anything queued on the ctx stream), a device buffer after everything queued on
+ * the ctx stream when it was released. Work the CALLER enqueues itself on a pinned buffer (its own hipMemcpyAsync) is not seen:
+ * finish it (paris_hip_ctx_synchronize, a fence) before releasing that buffer. */
 int paris_hip_malloc_host(paris_hip_ctx* ctx, size_t bytes, void** h_ptr);
 int paris_hip_free_host(paris_hip_ctx* ctx, void* h_ptr);
 /* 2-D copies, pitches in bytes; projection rows are dim_x floats */

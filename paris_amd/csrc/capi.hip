@@ -751,7 +751,8 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
         ctx->proj_allocs.erase(proj);
         paris_hip_forget_upload_target(ctx, d_ptr);
         bool parked = false;
-        if(int rc = pool_park(ctx, ctx->proj_pool, bytes, d_ptr, touched, ctx->stream, &parked))
+        (void)touched; // (an event always: work the caller enqueued on the ctx stream itself may use the buffer too)
+        if(int rc = pool_park(ctx, ctx->proj_pool, bytes, d_ptr, true, ctx->stream, &parked))
             return rc;
         if(parked)
             return PARIS_HIP_SUCCESS;
