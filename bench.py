@@ -109,7 +109,7 @@ def live_counters(argv_tail, launches=16, fused_batch=16):
     base = ["python3", os.path.join(ROOT, "bench.py")] + argv_tail + ["--live-traffic", "0", "--steps", "1", "--warmup", "0", "--spread", "1",
                                                                       "--cpu-budget", "0", "--cpu-c1", "0", "--noskip-step", "0"]
     single = base + ["--batch", str(launches), "--fused-steps", "0"]
-    fused = base + ["--batch", "1", "--fused-steps", "2", "--fused-batch", str(fused_batch)]
+    fused = base + ["--batch", "1", "--fused-steps", "2", "--fused-batch", str(fused_batch), "--deferred-leg", "0"]
     work = tempfile.mkdtemp(prefix="paris_pmc_", dir="/tmp")
 
     def one_pass(counter, child, kernel):
@@ -442,9 +442,10 @@ def main():
     ap.add_argument("--filter-deferral", type=int, default=1, help="deferred_boundary leg: 1 (default) = the filter() of each projection is "
                     "held back with its weight() and runs on the library's snapshots, one launch per group (paris_hip_set_filter_deferral: "
                     "what paris::hip switches on); 0 = one weight + filter launch per projection")
-    ap.add_argument("--overlap", type=int, default=0, help="deferred_boundary leg: 1 = fused launches of deferred calls on the ctx's "
-                    "second stream beside the next group's copies and filters (paris_hip_set_backproject_overlap); 0 (default, the "
-                    "library's default) = on the ctx stream")
+    ap.add_argument("--overlap", type=int, default=1, help="deferred_boundary leg: 1 (default: what the C++ mirror paris::hip runs) = "
+                    "fused launches of deferred calls on the ctx's second stream beside the next group's copies and filters "
+                    "(paris_hip_set_backproject_overlap); 0 (the bare library's default) = on the ctx stream. Config 1: 920 -> 1040-1050 "
+                    "GVox/s, configs 2-5 within noise (profiles/r04_ab_overlap_c1.txt, r04_ab_overlap_resident_c2.txt)")
     ap.add_argument("--live-traffic", type=int, default=1, help="1 (default; N = 1, config 3 only): roofline.traffic is measured in this "
                     "run -- before the GPU is touched, two child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` add 16 "
                     "projections spread over the circle each (about 20 s per pass); 0: the newest matching record under profiles/")
@@ -454,6 +455,9 @@ def main():
     ap.add_argument("--final-gather", choices=["checksums", "slabs", "off"], default="checksums",
                     help="N > 1, after the timed region and timed separately: the job's one collective. checksums (default): "
                     "all-gather of per-slab checksums; slabs: the slabs themselves gathered on rank 0 (4 GiB each at N = 8)")
+    ap.add_argument("--deferred-leg", type=int, default=1, help="0: the fused extension without the deferred_boundary leg -- every "
+                    "bp_fused_kernel launch of the run then adds exactly --fused-batch projections (counter passes normalise per launch; "
+                    "the deferred leg's first groups are launched early, after 8, 16 and 32 calls)")
     ap.add_argument("--workloads", type=int, default=1, help="1 (default; N = 1, the whole config-3 job only): after the headline's "
                     "measurements the other BASELINE configs are run as child processes and summarised under `workloads` "
                     "(config 1, config 2, config 4's slab shape, config 5 sampled)")
@@ -544,7 +548,7 @@ def main():
         be.set_backproject_variant(args.variant)
     # paris::weight is held back and rides along in the load of the paris::filter call that follows: one launch for the pair
     be.set_stage_fusion(bool(args.stage_fusion))
-    be.set_backproject_overlap(bool(args.overlap))
+    be.set_backproject_overlap(False)  # (the headline's one-launch-per-call steps have nothing to overlap; switched on for the deferred leg)
 
     n_row, n_col, n_proj = w["n_row"], w["n_col"], w["n_proj"]
     batch = args.batch if args.batch > 0 else -(-n_proj // max(1, args.steps))
@@ -751,28 +755,31 @@ def main():
         fused = {"steps": args.fused_steps, "seconds": tf, "kernel_ms": sum(fms) / max(1, len(fms)),
                  "kernel_ms_min": min(fms) if fms else 0.0, "kernel_ms_max": max(fms) if fms else 0.0}
 
-        # ---- the same per-projection calls as the headline, with the library's deferral switched on: every
-        # paris_hip_backproject call snapshots its projection, `batch` of them are added by one fused launch
-        be.set_backproject_deferral(fb)
-        be.set_filter_deferral(bool(args.filter_deferral) and not f16)
-        step(n_proj - fb, fb)
-        be.flush()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        td0 = time.perf_counter()
-        for first in starts:
-            step(first, fb)
-        td_host = time.perf_counter() - td0  # the host's share: every call has returned, the GPU may still be working
-        be.flush()
-        torch.cuda.synchronize()
-        barrier()
-        td = max_over_ranks(time.perf_counter() - td0)
-        be.set_filter_deferral(False)
-        be.set_backproject_deferral(1)
-        fused["deferred_seconds"] = td
-        fused["deferred_host_seconds"] = td_host
-        fused["deferred_projections"] = len(starts) * fb
+        if args.deferred_leg:
+            # ---- the same per-projection calls as the headline, with the library's deferral switched on: every
+            # paris_hip_backproject call snapshots its projection, `batch` of them are added by one fused launch
+            be.set_backproject_deferral(fb)
+            be.set_filter_deferral(bool(args.filter_deferral) and not f16)
+            be.set_backproject_overlap(bool(args.overlap))
+            step(n_proj - fb, fb)
+            be.flush()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            td0 = time.perf_counter()
+            for first in starts:
+                step(first, fb)
+            td_host = time.perf_counter() - td0  # the host's share: every call has returned, the GPU may still be working
+            be.flush()
+            torch.cuda.synchronize()
+            barrier()
+            td = max_over_ranks(time.perf_counter() - td0)
+            be.set_filter_deferral(False)
+            be.set_backproject_deferral(1)
+            be.set_backproject_overlap(False)
+            fused["deferred_seconds"] = td
+            fused["deferred_host_seconds"] = td_host
+            fused["deferred_projections"] = len(starts) * fb
 
     # ---- the job's one collective (north star: "no RCCL collective needed beyond a final gather"), timed on its own
     gather = None
@@ -917,10 +924,11 @@ def main():
                 out["deferred_boundary"] = {
                     "what": "the headline's step unchanged -- one paris_hip_backproject call per projection -- with "
                             "paris_hip_set_backproject_deferral(%d): the library snapshots each call's projection and adds %d of "
-                            "them per fused launch (bit-identical volume)%s; the call sequence of PARIS's per-projection loop with the projections resident on the device"
+                            "them per fused launch (the first groups of a sequence after 8, 16 and 32 calls; bit-identical volume)%s; the call sequence of PARIS's per-projection loop with the projections resident on the device"
                             % (fb, fb, ", and paris_hip_set_filter_deferral(1): each call pair weight() + filter() is held back and runs "
                                "on the snapshots, one launch per group" if (args.filter_deferral and not f16) else ""),
                     "filter_deferral": bool(args.filter_deferral and not f16),
+                    "second_stream": bool(args.overlap),
                     "value": voxels_all * fused["deferred_projections"] / fused["deferred_seconds"] / 1e9,
                     "unit": "GVoxel-updates/s",
                     # how long the calls themselves took to return (Python + ctypes + HIP enqueue): close to 1 = the leg is bound

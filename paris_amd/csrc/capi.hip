@@ -135,8 +135,14 @@ extern "C" int paris_hip_ctx_create(int device, void* stream, unsigned flags, pa
 
 int paris_hip_ensure_aux(paris_hip_ctx* ctx)
 {
+    // the validators borrow the upload stream (library-owned, never captured by the caller; a check waits for the uploads queued
+    // before it, milliseconds at most, once per detector): creating a stream costs 2-40 ms, one fewer per ctx
     if(ctx->aux_stream == nullptr)
-        PARIS_HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    {
+        if(int rc = paris_hip_ensure_upload_stream(ctx))
+            return rc;
+        ctx->aux_stream = ctx->upload_stream;
+    }
     if(ctx->aux_counter == nullptr)
         PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->aux_counter), sizeof(unsigned long long)));
     return PARIS_HIP_SUCCESS;
@@ -279,11 +285,7 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
         (void)hipStreamDestroy(ctx->bp_stream);
         ctx->bp_stream = nullptr;
     }
-    if(ctx->aux_stream != nullptr)
-    {
-        (void)hipStreamSynchronize(ctx->aux_stream);
-        (void)hipStreamDestroy(ctx->aux_stream);
-    }
+    ctx->aux_stream = nullptr; // (the upload stream under another name: destroyed below)
     if(ctx->aux_counter != nullptr)
         (void)hipFree(ctx->aux_counter);
     for(auto& kv : ctx->plans)

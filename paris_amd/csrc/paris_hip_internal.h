@@ -158,9 +158,10 @@ struct paris_hip_ctx
         const size_t by_bytes = bytes ? (size_t{64} << 20) / bytes : 16u;
         return by_bytes < 8u ? 8u : (by_bytes > 16u ? 16u : by_bytes);
     }
-    // validators (backproject.hip: fast division; validate.hip) run on a stream of their own -- never the caller's, which may be
-    // capturing or hold queued work the caller does not want to wait for -- with an 8-byte mismatch counter; made on first use
-    // (or by PARIS_HIP_CTX_WARM) and kept: creating and destroying a stream per check cost more than the checks
+    // validators (backproject.hip: fast division; validate.hip) never run on the caller's stream -- it may be capturing, or hold
+    // queued work the caller does not want to wait for -- but on the ctx's upload stream (aux_stream is its alias), with an 8-byte
+    // mismatch counter; made on first use (or by PARIS_HIP_CTX_WARM) and kept: creating and destroying a stream per check cost
+    // more than the checks
     hipStream_t aux_stream = nullptr;
     unsigned long long* aux_counter = nullptr;
     std::vector<hipEvent_t> spare_events; // timing-disabled events ready for reuse (pool releases, upload targets)

@@ -123,6 +123,26 @@ def test_cpp_loop_second_stream_equals_one_stream_and_one_launch_per_call(tmp_pa
     assert np.array_equal(vols[0].view(np.uint32), vols[2].view(np.uint32))
 
 
+def test_cpp_loop_with_the_host_ahead_of_the_device(tmp_path):
+    """The pools' blocking path: small frames (512 x 512: the host supplies one in ~70 us) into a large volume (1024 x 1024 x 512:
+    the device needs ~270 us per projection), so the host runs ahead until every buffer of the rotation is parked and busy and
+    paris_hip_malloc_* waits for the oldest one -- its H2D copy for a pinned buffer, its snapshot for a device buffer -- while
+    fused launches run on the second stream and the ring's halves alternate. 130 projections (8 + 16 + 32 + 48 + 26). The
+    volume equals the one-launch-per-call build's bit for bit."""
+    args = ["512", "512", "0.2", "0.2", "0", "0", "500", "500", "2.769", "130"]
+    vols = []
+    for exe in (DEMO, DEMO + "_immediate"):
+        if not os.path.exists(exe):
+            pytest.fail("%s missing: run __graft_entry__.build()" % exe)
+        out = tmp_path / (os.path.basename(exe) + ".raw")
+        r = subprocess.run([exe] + args + ["lcg", str(out), "--vol", "1024", "1024", "512", "0.05"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        vols.append(np.fromfile(out, np.float32))
+        os.unlink(out)
+    assert vols[0].size == 1024 * 1024 * 512 and np.abs(vols[0]).max() > 0
+    assert np.array_equal(vols[0].view(np.uint32), vols[1].view(np.uint32))
+
+
 def test_flush_rules_at_config3_size():
     """the deferred boundary (16 backproject() calls per fused launch) and the held-back weight() through the
     C++ mirror paris::hip on the 2048^2 detector / 2048^3 grid of BASELINE config 3, with every observer that must flush

@@ -18,7 +18,7 @@ run rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/prof_fetch -- python3
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/prof_write -- python3 bench.py $A > /dev/null
 python tools/pmc_traffic.py $out/prof_fetch $out/prof_write "2048^3 volume, 1440 projections @ 2048x2048 fp32" $out/${tag}_pmc_traffic_c3.json
 echo "traffic done" >&2
-S="--steps 1 --warmup 1 --batch 8 --spread 1 --cpu-budget 0 --cpu-c1 0 --noskip-step 0 --live-traffic 0 --fused-steps 1"
+S="--steps 1 --warmup 1 --batch 8 --spread 1 --cpu-budget 0 --cpu-c1 0 --noskip-step 0 --live-traffic 0 --fused-steps 2 --deferred-leg 0"
 run rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $out/pmc_sq_a -- python3 bench.py $S > /dev/null
 run rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_sq_b -- python3 bench.py $S > /dev/null
 python tools/pmc_sq.py $out/pmc_sq_a $out/pmc_sq_b $out/quick.json $out/${tag}_pmc_sq_counters_c3.json "$S"
