@@ -116,6 +116,62 @@ def test_final_gather_and_placement(tmp_path, world):
     assert shared == 1.0 and exclusive_raises == 1.0 and n == world  # every rank reported, all on one (shared) device
 
 
+def _wave_worker(rank, world, port, as_world, base, result_path):
+    """bench.py --as-world / --as-rank-base: `world` processes play ranks base .. base + world - 1 of an as_world-rank partition"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle as O
+    from paris_amd import backend as B
+    from paris_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = (64, 48, 0.2, 0.25, 1.5, -0.75, 100, 200, 45)
+    det, odet = B.DetectorGeometry(*g), O.DetectorGeometry(*g)
+    vg = B.calculate_volume_geometry(det)
+    ovg = O.calculate_volume_geometry(odet)
+    info = sharding.make_subvolume_info(vg, as_world)
+    z_first, z_count = sharding.slab_of_task(info, base + rank)
+    slab = torch.from_numpy(O.reconstruct(odet, ovg, 3, v_dims=(z_count, vg.dim_y, vg.dim_x), v_offset=z_first))
+    full = sharding.final_gather(dist, slab, info, rank, world, full=True, on_device=False, task_base=base)
+    if rank == 0:
+        want = O.reconstruct(odet, ovg, 3)
+        parts, counts = full["volume"]
+        got = np.concatenate([parts[t][:counts[t]].numpy() for t in range(world)])
+        first = sharding.slab_of_task(info, base)[0]
+        np.save(result_path, np.array([float(np.array_equal(got, want[first:first + sum(counts)])), float(full["gathered_matches_checksums"]),
+                                       float(counts == [sharding.slab_of_task(info, base + t)[1] for t in range(world)])] + full["checksums"]))
+    dist.destroy_process_group()
+
+
+def test_an_eight_rank_partition_in_two_waves_of_four(tmp_path):
+    """The rehearsal of the 8-GPU job on a pool that admits fewer processes per card (bench.py --as-world 8 --as-rank-base 0 / 4,
+    tests/test_gpu_bench_contract.py): four processes play ranks 0-3, then 4-7, of the 8-rank partition (61 slices: 7 per rank,
+    the last one 12); each wave's gather assembles its half, and the eight checksums are those of the single-rank volume's blocks."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from paris_amd import sharding
+    from paris_amd import backend as B
+    sums = []
+    for base in (0, 4):
+        result = str(tmp_path / ("w%d.npy" % base))
+        mp.spawn(_wave_worker, args=(4, _free_port(), 8, base, result), nprocs=4, join=True)
+        r = np.load(result)
+        assert r[0] == 1.0 and r[1] == 1.0 and r[2] == 1.0
+        sums += list(r[3:])
+    g = (64, 48, 0.2, 0.25, 1.5, -0.75, 100, 200, 45)
+    odet = O.DetectorGeometry(*g)
+    ovg = O.calculate_volume_geometry(odet)
+    want = O.reconstruct(odet, ovg, 3)
+    info = sharding.make_subvolume_info(B.calculate_volume_geometry(B.DetectorGeometry(*g)), 8)
+    blocks = [float(want[z0:z0 + zc].sum(dtype=np.float64)) for z0, zc in (sharding.slab_of_task(info, t) for t in range(8))]
+    assert len(sums) == 8 and all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for a, b in zip(sums, blocks))
+
+
 def test_device_of_rank():
     sys.path.insert(0, ROOT)
     from paris_amd import sharding
