@@ -162,7 +162,7 @@ def other_workloads(common_tail):
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv + common_tail
                                + ["--cpu-budget", "0", "--cpu-c1", "0", "--live-traffic", "0", "--workloads", "0"],
-                               cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                               cwd=ROOT, env=env, capture_output=True, text=True, timeout=150)  # (2-10 s each; bounded)
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not lines:
                 out[name] = {"error": (r.stderr or "no JSON line")[-300:]}
