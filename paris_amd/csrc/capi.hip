@@ -458,7 +458,7 @@ namespace
     using pool_t = std::multimap<size_t, paris_hip_ctx::pooled_buffer>;
 
     // takes the oldest released buffer of `bytes` if it is free to use (or if that size's share of the pool is full: then waits for it)
-    int pool_take(paris_hip_ctx* ctx, pool_t& pool, size_t bytes, void** out)
+    int pool_take(paris_hip_ctx* ctx, pool_t& pool, size_t bytes, size_t capacity, void** out)
     {
         *out = nullptr;
         auto it = pool.lower_bound(bytes);
@@ -470,7 +470,7 @@ namespace
             if(state == hipErrorNotReady)
             {
                 (void)hipGetLastError();
-                if(pool.count(bytes) < paris_hip_ctx::pool_capacity(bytes))
+                if(pool.count(bytes) < capacity)
                     return PARIS_HIP_SUCCESS; // let the caller allocate another one; the rotation grows up to the capacity
                 PARIS_HIP_TRY(hipEventSynchronize(it->second.released));
             }
@@ -485,10 +485,10 @@ namespace
 
     // parks a buffer behind its last user: an event recorded on `last` now (everything enqueued there so far), or none at all
     // when nothing used the buffer (last == nullptr and !used); false when that size's share of the pool is full
-    int pool_park(paris_hip_ctx* ctx, pool_t& pool, size_t bytes, void* ptr, bool used, hipStream_t last, bool* parked)
+    int pool_park(paris_hip_ctx* ctx, pool_t& pool, size_t bytes, size_t capacity, void* ptr, bool used, hipStream_t last, bool* parked)
     {
         *parked = false;
-        if(pool.count(bytes) >= paris_hip_ctx::pool_capacity(bytes))
+        if(pool.count(bytes) >= capacity)
             return PARIS_HIP_SUCCESS;
         hipEvent_t e = nullptr;
         if(used)
@@ -523,7 +523,7 @@ extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, u
     const size_t row = (static_cast<size_t>(dim_x) * sizeof(float) + 255u) & ~static_cast<size_t>(255u);
     const size_t bytes = row * dim_y;
     void* p = nullptr;
-    if(int rc = pool_take(ctx, ctx->proj_pool, bytes, &p))
+    if(int rc = pool_take(ctx, ctx->proj_pool, bytes, paris_hip_ctx::device_pool_capacity(bytes), &p))
         return rc;
     if(p == nullptr)
         PARIS_HIP_TRY(hipMalloc(&p, bytes));
@@ -754,7 +754,7 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
         paris_hip_forget_upload_target(ctx, d_ptr);
         bool parked = false;
         (void)touched; // (an event always: work the caller enqueued on the ctx stream itself may use the buffer too)
-        if(int rc = pool_park(ctx, ctx->proj_pool, bytes, d_ptr, true, ctx->stream, &parked))
+        if(int rc = pool_park(ctx, ctx->proj_pool, bytes, paris_hip_ctx::device_pool_capacity(bytes), d_ptr, true, ctx->stream, &parked))
             return rc;
         if(parked)
             return PARIS_HIP_SUCCESS;
@@ -814,7 +814,7 @@ extern "C" int paris_hip_malloc_host(paris_hip_ctx* ctx, size_t bytes, void** h_
         return rc;
     if(h_ptr == nullptr || bytes == 0)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    if(int rc = pool_take(ctx, ctx->host_pool, bytes, h_ptr))
+    if(int rc = pool_take(ctx, ctx->host_pool, bytes, paris_hip_ctx::pool_capacity(bytes), h_ptr))
         return rc;
     if(*h_ptr == nullptr)
         PARIS_HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
@@ -841,7 +841,7 @@ extern "C" int paris_hip_free_host(paris_hip_ctx* ctx, void* h_ptr)
         // every upload (paris_hip_upload_projection), so its tail covers them.
         hipStream_t last = (used == paris_hip_ctx::USED_UPLOAD && ctx->upload_stream != nullptr) ? ctx->upload_stream : ctx->stream;
         bool parked = false;
-        if(int rc = pool_park(ctx, ctx->host_pool, bytes, h_ptr, used != 0u, last, &parked))
+        if(int rc = pool_park(ctx, ctx->host_pool, bytes, paris_hip_ctx::pool_capacity(bytes), h_ptr, used != 0u, last, &parked))
             return rc;
         if(parked)
             return PARIS_HIP_SUCCESS;

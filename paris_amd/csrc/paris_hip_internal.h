@@ -147,16 +147,24 @@ struct paris_hip_ctx
     std::map<void*, host_alloc> host_allocs;           // live pinned buffers of paris_hip_malloc_host up to POOL_HOST_BYTES
     std::multimap<size_t, pooled_buffer> host_pool;
     static constexpr size_t POOL_HOST_BYTES = size_t{64} << 20; // a 4096 x 4096 frame
-    // How far the host may run ahead of the device in buffers of one size: 8 at least, up to 64 MiB worth, 16 at most (a caller
-    // that allocates and frees a buffer per projection blocks in paris_hip_malloc_* once that many are parked and busy). Deep
-    // enough that the device never waits for such a caller -- the rest of a group of deferred projections is supplied while the
-    // previous group's fused launch runs -- and no deeper: a host that is faster than the device grows the rotation to its
-    // capacity in the first milliseconds, and pinning a buffer costs ~0.25 ms per MiB (64 buffers of a 1024^2 frame: 60 ms of a
-    // 500 ms job, measured).
+    // How far the host may run ahead of the device in PINNED buffers of one size: 8 at least, up to 64 MiB worth, 16 at most (a caller
+    // that allocates and frees a buffer per projection blocks in paris_hip_malloc_host once that many are parked and busy). A pinned
+    // buffer is busy only until its own H2D copy is done, so a few suffice, and pinning costs ~0.25 ms per MiB (64 buffers of a
+    // 1024^2 frame: 60 ms of a 500 ms job, measured).
     static constexpr size_t pool_capacity(size_t bytes)
     {
         const size_t by_bytes = bytes ? (size_t{64} << 20) / bytes : 16u;
         return by_bytes < 8u ? 8u : (by_bytes > 16u ? 16u : by_bytes);
+    }
+    // DEVICE projection buffers stay busy until the compute stream has run their filter and snapshot -- beside a running fused
+    // launch that takes milliseconds per frame (the filter's waves do not fit next to the fused kernel's) -- so the rotation holds
+    // a whole group of deferred projections and a few more, as far as 2 GiB go: a host that supplies frames faster than that trickle
+    // keeps filling while the launch runs, and the backlog drains in a millisecond once the launch ends (2048^2 frames into a
+    // 256-slice slab, filter in place: the loop waited 0.38 ms per frame on its 8 buffers). Device allocations cost ~0.1 ms each.
+    static constexpr size_t device_pool_capacity(size_t bytes)
+    {
+        const size_t by_bytes = bytes ? (size_t{2} << 30) / bytes : 56u;
+        return by_bytes < 8u ? 8u : (by_bytes > 56u ? 56u : by_bytes);
     }
     // validators (backproject.hip: fast division; validate.hip) never run on the caller's stream -- it may be capturing, or hold
     // queued work the caller does not want to wait for -- but on the ctx's upload stream (aux_stream is its alias), with an 8-byte

@@ -26,9 +26,12 @@
 // library's snapshots, one launch per group of deferred backprojections (paris_hip_set_filter_deferral: what small projections
 // need when the GPU is the limit -- their single launches are mostly latency). The projection's own buffer then keeps its
 // unfiltered pixels; PARIS's loop destroys it right after backproject() (src/main.cpp:98-105). 0 (default): the filter runs when
-// it is called -- PARIS's own loop allocates, fills and uploads a host projection per iteration and is bound by that as much as by
-// the GPU, so the switch buys it little (1536 projections of 512^2: 906-911 against 876-882 GVox/s; 720 of 1024^2: 1299-1303
-// against 1297-1299; same box interleaved), not enough to change what the caller's buffer holds behind its back.
+// it is called, in place -- the switch would change what the caller's buffer holds behind its back, and it buys PARIS's loop nothing
+// that the buffer rotation does not: a per-projection filter launch cannot share the chip with a running fused launch (its waves do
+// not fit beside four fused waves per SIMD; 3.3-3.8 ms per 2048^2 frame instead of 19 us), and with 8 device buffers in rotation the
+// loop stalled on them where a group's launch is short (2048^2 frames into the 256-slice slab of the 8-GPU configuration: 1138 GVox/s
+// against 1847 with the switch); since the rotation holds a whole group (device_pool_capacity) both ways run at the host's own
+// frame rate there (1790-1850), and everywhere else they measure the same (profiles/r04_ab_filter_deferral_in_the_mirror.txt).
 #ifndef PARIS_HIP_FILTER_DEFERRAL
 #define PARIS_HIP_FILTER_DEFERRAL 0
 #endif
