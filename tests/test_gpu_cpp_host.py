@@ -54,7 +54,7 @@ def test_cpp_loop_one_launch_per_call(tmp_path, gold):
 
 @pytest.mark.parametrize("exe", [DEMO, DEMO + "_immediate"])
 def test_cpp_loop_many_projections_rotating_buffers(tmp_path, oracle, exe):
-    """40 projections of 200 x 160 through the asynchronous loop: the deferral ring fills and flushes twice (16 + 16 + 8 at
+    """40 projections of 200 x 160 through the asynchronous loop: the deferral ring is launched after 8, then 16 more calls (8 + 16 + 16 at
     read-back), released host / device projection buffers rotate through the library's pools while earlier uploads and
     launches are still in flight. Bit-identical to the oracle's backprojection of the same frames."""
     n_row, n_col, n_proj = 200, 160, 40
@@ -144,7 +144,7 @@ def test_cpp_loop_with_the_host_ahead_of_the_device(tmp_path):
 
 
 def test_flush_rules_at_config3_size():
-    """the deferred boundary (16 backproject() calls per fused launch) and the held-back weight() through the
+    """the deferred boundary (48 backproject() calls per fused launch; a sequence's first groups after 8, 16, 32 calls) and the held-back weight() through the
     C++ mirror paris::hip on the 2048^2 detector / 2048^3 grid of BASELINE config 3, with every observer that must flush
     interleaved (copy_d2h in the middle of a group, calls alternating between two slabs, make / free of other buffers,
     synchronize, a projection read between weight and filter): every read-back equals the one-launch-per-call run bit for bit;
