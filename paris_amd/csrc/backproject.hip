@@ -754,7 +754,18 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         }
         // slices in flight per lane: 2 (interleaved A/B on 2048^3: tools/ab_bp.py, profiles/); with the 8-slice tiles of
         // 1024^2 planes one slice plus the prefetch of the next is as fast and leaves more registers
-        const int unroll = ctx->bp_unroll ? ctx->bp_unroll : (g.tz == 8u && ctx->bp_tz == 0u ? 1 : 2);
+        // Deep volumes on planes beyond 1024^2 (16-slice tiles): ONE slice in flight per lane and FOUR workgroups per CU -- the
+        // registers of the one-slice body would admit five, so the launch asks for 40 KiB of LDS per workgroup (160 / 40 = 4; the
+        // box budget grows with it). Round 4, same device: 2048^3 0.7841-0.7850 -> 0.7919-0.7931 of the HBM peak, the 2048^3 ROI of
+        // config 5 0.7424 -> 0.7640; with five workgroups 0.780, with three 0.705, two slices in flight at four (rounds 1-3) 0.785,
+        // a prefetched next slice 0.763. This stream runs fastest with FEW requests in flight -- as many as hide the latency and no
+        // more: what sets its rate is the order in which the tiles' requests reach DRAM (profiles/r04_ab_tile_occupancy.txt,
+        // r04_ab_tile_prefetch.txt). 8-slice tiles (slabs up to 512 slices, planes up to 1024^2) keep one slice at five: 0.765
+        // against 0.711 at four.
+        const bool deep_big = g.tz == 16u && ctx->bp_tz == 0u && static_cast<uint64_t>(v_dim_x) * v_dim_y > (1ull << 20);
+        if(deep_big && ctx->bp_unroll == 0 && ctx->bp_lds_bytes == 0u && vx == 4)
+            g.lds_floats = 40u * 1024u / sizeof(float);
+        const int unroll = ctx->bp_unroll ? ctx->bp_unroll : ((g.tz == 8u && ctx->bp_tz == 0u) || (deep_big && ctx->bp_lds_bytes == 0u && vx == 4) ? 1 : 2);
         const bool nt = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) != 0;
         const bool want_slice = ctx->bp_variant == 3; // measured slower than the tile kernel so far: opt-in only
         if(want_slice && vx == 4)
