@@ -590,7 +590,10 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
     // lost its integer divisions: +0.65 % on one device, -1.2 % on the next, profiles/r02_ab_tile_depth_full_volume.txt). Planes up to 1024^2: order 5 with 8-slice
     // tiles (+2.5 %; the band orders lose 3 %), up to 512^2 with 16-slice tiles.
     const uint64_t plane = static_cast<uint64_t>(v_dim_x) * v_dim_y;
-    const uint32_t tz_auto = plane > (1ull << 20) ? (v_dim_z <= 512u ? 8u : TZ_DEFAULT) : (plane > (1ull << 18) ? 8u : TZ_DEFAULT);
+    // (round 4: the 8-slice tiles of large planes end at 256 slices, not 512 -- with one slice in flight at four workgroups per CU the
+    // 16-slice tiles win above that: 2048 x 2048 x 512 0.743-0.759 -> 0.759-0.763, x 352 +2 %, x 320 +0.6 %, x 288 +0.5 %; at 256 the two
+    // are within +-0.3 % of each other by device and the slab keeps its 8-slice tiles; profiles/r04_ab_tile_occupancy.txt section 6)
+    const uint32_t tz_auto = plane > (1ull << 20) ? (v_dim_z <= 256u ? 8u : TZ_DEFAULT) : (plane > (1ull << 18) ? 8u : TZ_DEFAULT);
     const uint32_t tz = ctx->bp_tz ? ctx->bp_tz : tz_auto;
     {
         // the 1-D grid must hold every tile of the narrowest, shallowest tiling any kernel uses (64 x 4 x min(tz, 8)), INCLUDING
