@@ -679,7 +679,7 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
         // 0.7774, 0.7757 -> 0.7784; the 2048^3 ROI of config 5: 0.7387 -> 0.7396, 0.7384 -> 0.7400), a 256-slice slab keeps the z tile
         // first (0.7584 -> 0.7565, 0.7572 -> 0.7540 with the other nesting); same device, interleaved, profiles/r03_ab_tile_order.txt
         static const int tile_nest = std::getenv("PARIS_TILE_NEST") ? std::atoi(std::getenv("PARIS_TILE_NEST")) : -1; // A/B switch
-        g.yfast = tile_nest >= 0 ? static_cast<uint32_t>(tile_nest) : (v_dim_z > 512u ? 2u : 0u);
+        g.yfast = tile_nest >= 0 ? static_cast<uint32_t>(tile_nest) : (v_dim_z > 256u ? 2u : 0u); // (round 4: with the 16-slice tiles, from 257 slices: +0.15 % at 512, +0.25 % at 1024)
     }
     // (y tiles fastest is for the fused kernel's box sharing; the volume stream of this kernel loses with it: 2048^3 0.772 -> 0.662, 1024^3 0.743 -> 0.567)
     g.order = ctx->bp_order >= 0 ? static_cast<uint32_t>(ctx->bp_order) : (plane > (1ull << 20) ? 15u : 18u); // (18 falls back to 5 for volumes of fewer than 8 z tiles: settle_order)
