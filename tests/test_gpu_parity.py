@@ -2144,9 +2144,9 @@ def test_per_projection_buffers_through_the_pools_beside_the_fused_launch(oracle
     synchronising in between; with overlap the fused launches run on the second stream. Released buffers come back from the
     pools only when their last user has finished: a pinned buffer after its own H2D copy, a device buffer after its snapshot.
     The host overwrites every pinned buffer it gets at once -- if one came back early the frame in flight would be corrupted.
-    1024 x 64 frames into a 1024 x 1024 x 24 slab (launches long enough to still run when the next buffers are taken), 26
-    projections. Equal bit for bit to the run that synchronises after every call."""
-    n, rows, n_proj = 1024, 64, 26
+    1024 x 64 frames into a 1024 x 1024 x 24 slab (launches long enough to still run when the next buffers are taken), 70
+    projections (the rotations hold at most 16 pinned and 56 device buffers of this size). Equal bit for bit to the run that synchronises after every call."""
+    n, rows, n_proj = 1024, 64, 70   # (more projections than either rotation can hold: buffers MUST come back from the pools)
     det = B.DetectorGeometry(n, rows, 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 360.0 / n_proj)
     nat = B.calculate_volume_geometry(det)
     vg = B.VolumeGeometry(n, n, 24, nat.l_vx_x, nat.l_vx_x, nat.l_vx_z)
