@@ -107,7 +107,7 @@ def live_counters(argv_tail, launches=16, fused_batch=16):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     base = ["python3", os.path.join(ROOT, "bench.py")] + argv_tail + ["--live-traffic", "0", "--steps", "1", "--warmup", "0", "--spread", "1",
-                                                                      "--cpu-budget", "0", "--cpu-c1", "0", "--noskip-step", "0"]
+                                                                      "--cpu-budget", "0", "--cpu-c1", "0", "--noskip-step", "0", "--workloads", "0", "--paris-loop", "0"]
     single = base + ["--batch", str(launches), "--fused-steps", "0"]
     fused = base + ["--batch", "1", "--fused-steps", "2", "--fused-batch", str(fused_batch), "--deferred-leg", "0"]
     work = tempfile.mkdtemp(prefix="paris_pmc_", dir="/tmp")
@@ -161,7 +161,7 @@ def other_workloads(common_tail):
         t0 = time.perf_counter()
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv + common_tail
-                               + ["--cpu-budget", "0", "--cpu-c1", "0", "--live-traffic", "0", "--workloads", "0"],
+                               + ["--cpu-budget", "0", "--cpu-c1", "0", "--live-traffic", "0", "--workloads", "0", "--paris-loop", "0"],
                                cwd=ROOT, env=env, capture_output=True, text=True, timeout=150)  # (2-10 s each; bounded)
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not lines:
@@ -182,6 +182,62 @@ def other_workloads(common_tail):
         if "frac_of_cache_resident_rate" in rf:
             e["roofline"]["frac_of_cache_resident_rate"] = rf["frac_of_cache_resident_rate"]
         out[name] = e
+    return out
+
+
+PARIS_LOOP_JOBS = [
+    # (key, n, projections, explicit volume or None = the natural volume of an n x n detector)
+    ("1440x2048^2->natural_2048x2048x2090", 2048, 1440, None),
+    ("720x1024^2->natural_1024x1024x1029", 1024, 720, None),
+    ("360x512^2->512^3", 512, 360, None),
+    ("360x512^2->256^3_config1", 512, 360, (256, 256, 256, 2.0)),
+]
+
+
+def paris_loop(budget_s=40.0):
+    """PARIS's own per-projection loop (/root/reference/src/main.cpp:98-105: make_projection_host / fill / load / weight / filter /
+    backproject / free per projection, frames uploaded from pinned host memory: /root/reference/src/loader.cpp:28-33) through the C++
+    mirror paris::hip, as child processes of paris_amd/host/demo/paris_hip_demo (built by build()): whole circles, from the first call
+    to the end of the GPU work. The volume is neither read back nor written; 48 distinct noise frames are cycled. Each job reports
+    the loop's rate, the host's own frame fill, the backend calls' share and the time of every call of one iteration."""
+    import subprocess
+    exe = os.path.join(ROOT, "paris_amd", "host", "demo", "paris_hip_demo")
+    if not os.path.exists(exe):
+        return {"error": "paris_hip_demo is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    import numpy as np
+    out = {}
+    t_all = time.perf_counter()
+    for key, n, n_proj, vol in PARIS_LOOP_JOBS:
+        if time.perf_counter() - t_all > budget_s:
+            out[key] = {"error": "skipped: the leg's time budget was spent"}
+            continue
+        argv = [exe, str(n), str(n), "0.2", "0.2", "0", "0", "500", "500", repr(360.0 / n_proj), str(n_proj), "lcg", "/dev/null",
+                "--cycle", "48", "--no-out", "--json"]
+        if vol is not None:
+            # the config's own voxel size: l_nat x (n_row / dim_x), as geometry() derives it for the other legs
+            from paris_amd import backend as B
+            det = B.DetectorGeometry(n, n, 0.2, 0.2, 0.0, 0.0, 500.0, 500.0, 360.0 / n_proj)
+            l_vx = float(np.float32(B.calculate_volume_geometry(det).l_vx_x) * np.float32(vol[3]))
+            argv += ["--vol", str(vol[0]), str(vol[1]), str(vol[2]), repr(l_vx)]
+        best = None
+        t0 = time.perf_counter()
+        try:
+            for _ in range(1 if n >= 2048 else 2):  # (small jobs twice, the better run: a process start-up may land in the first)
+                r = subprocess.run(argv, cwd=ROOT, capture_output=True, text=True, timeout=120)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not lines:
+                    best = {"error": (r.stderr or r.stdout or "no JSON line")[-300:]}
+                    break
+                d = json.loads(lines[-1])
+                if best is None or d["value"] > best["value"]:
+                    best = d
+        except (OSError, subprocess.SubprocessError, ValueError) as e:
+            best = {"error": str(e)[:300]}
+        if "error" not in best:
+            best["host_fill_share"] = best["host_fill_seconds"] / best["seconds"]
+            best["backend_call_share"] = best["backend_call_seconds"] / best["seconds"]
+            best["wall_seconds_of_the_child_runs"] = time.perf_counter() - t0
+        out[key] = best
     return out
 
 
@@ -399,6 +455,47 @@ def octant_stats(kernel_ms, idx_of_launch, n_proj):
     return out
 
 
+def launch_ranks(args, argv):
+    """`python3 bench.py --gpus N` with N > 1 and no RANK in the environment: the job starts itself. One rank per GPU is started
+    through torch.distributed.run as an ordinary CHILD process (this process never touches the GPU: counting devices does not
+    initialise it, and nothing is exec'ed), rank 0's one JSON line is relayed to stdout, the launcher's exit status is returned.
+    Stands where the reference fans out one thread per device (/root/reference/src/main.cpp:157-167)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if args.dist_backend == "nccl":
+        import torch
+        visible = torch.cuda.device_count()
+        if visible < n:
+            sys.stderr.write("bench.py: --gpus %d over nccl (= RCCL) needs one GPU per rank, %d visible: nothing was run "
+                             "(a rehearsal with ranks sharing a card: --dist-backend gloo --device 0)\n" % (n, visible))
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes fails without it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--max-restarts", "0",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)  # (stderr is inherited)
+    line = None
+    for text in child.stdout:
+        if text.startswith("{"):
+            line = text
+        elif text.strip():
+            sys.stderr.write(text)
+    rc = child.wait()
+    if line is not None:
+        sys.stdout.write(line if line.endswith("\n") else line + "\n")
+        sys.stdout.flush()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks ended without a JSON line\n")
+        return 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -468,7 +565,15 @@ def main():
     ap.add_argument("--as-rank-base", type=int, default=0)
     ap.add_argument("--block-checksums", type=int, default=0, help="N = 1: also report the float64 sum of each of this many z blocks "
                     "of the volume (the reference's split rule), i.e. the slab checksums an N-rank run of the same projections must reproduce")
+    ap.add_argument("--dist-timeout", type=float, default=120.0, help="seconds a rank waits in the rendezvous (init_process_group) "
+                    "before it gives up: one dead rank ends the run instead of hanging the others until the caller's limit")
+    ap.add_argument("--paris-loop", type=int, default=1, help="1 (default; N = 1, the whole config-3 job only): PARIS's own per-projection "
+                    "loop through the C++ mirror (paris_hip_demo, child processes) is timed for four jobs and reported as `paris_loop`")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # called the way the N = 1 line is (`python3 bench.py --gpus N ...`): this process becomes the launcher
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     # stdout carries ONE JSON line and nothing else: libraries that print there from native code (RCCL's version banner at
     # communicator creation, the ROCm runtime) are sent to stderr for the life of the process; the line is written to the
@@ -506,10 +611,20 @@ def main():
     dist = None
     if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # under torch.distributed.run, also at N = 1
         import torch.distributed as dist
+        import datetime
+        limit = datetime.timedelta(seconds=max(10.0, args.dist_timeout))
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+            if n_visible < world:  # (the launcher checks too; this is the torchrun-started path)
+                raise SystemExit("bench.py: %d ranks over nccl (= RCCL) need one GPU each, %d visible" % (world, n_visible))
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=limit)  # nccl == RCCL on ROCm
         else:
-            dist.init_process_group(backend=args.dist_backend)
+            dist.init_process_group(backend=args.dist_backend, timeout=limit)
+        # the rendezvous is over: the job's own collectives (barriers around the timed region, the final gather) may wait longer
+        # for a rank that is merely slow than for one that never arrived
+        try:
+            dist.distributed_c10d._set_pg_timeout(datetime.timedelta(seconds=max(600.0, args.dist_timeout)))
+        except (AttributeError, RuntimeError, TypeError):
+            pass
         # every rank must sit on a GPU of its own (RCCL needs it; a wrapped LOCAL_RANK would silently halve the job's HBM)
         placement = sharding.gather_placement(dist, dev_index, torch.cuda.get_device_properties(dev_index))
         sharding.check_placement(placement, exclusive=(args.dist_backend == "nccl"))
@@ -954,7 +1069,7 @@ def main():
             out["cpu_baseline"]["cpu_model"] = cpu_model()
             if args.cpu_c1:
                 out["cpu_baseline_c1"] = cpu_baseline_c1()
-        if (args.workloads and world == 1 and dist is None and args.workload == "c3" and args.slices == 0 and args.batch == 0
+        if ((args.workloads or args.paris_loop) and world == 1 and dist is None and args.workload == "c3" and args.slices == 0 and args.batch == 0
                 and not under_profiler):
             # the headline is complete: free its 32 GiB slab and stacks, then the other configs, one child at a time
             be.free(d_vol)
@@ -963,7 +1078,10 @@ def main():
             tail = []
             for name in ("vx", "unroll", "tz", "lds_bytes", "variant", "order", "row_band", "stage_fusion", "fused_batch"):
                 tail += ["--" + name.replace("_", "-"), str(getattr(args, name))]
-            out["workloads"] = other_workloads(tail)
+            if args.workloads:
+                out["workloads"] = other_workloads(tail)
+            if args.paris_loop:
+                out["paris_loop"] = paris_loop()
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 

@@ -3,10 +3,11 @@
 //
 // usage: paris_hip_demo <n_row> <n_col> <l_px_row> <l_px_col> <delta_s> <delta_t> <d_so> <d_od> <delta_phi>
 //                       <n_proj> <in.raw | lcg> <out.raw> [--no-weight] [--no-filter]
-//                       [--slabs N] [--roi x1 x2 y1 y2 z1 z2] [--vol dx dy dz l_vx] [--cycle K] [--no-out] [--order N]
+//                       [--slabs N] [--roi x1 x2 y1 y2 z1 z2] [--vol dx dy dz l_vx] [--cycle K] [--no-out] [--order N] [--json]
 // in.raw holds n_proj frames of n_col x n_row float32; "lcg" generates the SURVEY.md 8c noise frames.
 // --cycle K: only K distinct lcg frames are held in host memory and projection i is frame i mod K (throughput runs over a whole
 // circle of large frames: 1440 frames of 2048^2 would be 23 GiB); --no-out: the volume is neither read back nor written to out.raw.
+// --json: one more line, the same figures as a JSON object (bench.py's paris_loop leg reads it).
 // out.raw receives the whole (ROI) volume, slabs written at their slice offsets (fixing SURVEY.md Q4).
 #include <chrono>
 #include <cstdio>
@@ -53,7 +54,7 @@ int main(int argc, char** argv)
         const auto in_path = std::string{argv[11]};
         const auto out_path = std::string{argv[12]};
 
-        bool do_weight = true, do_filter = true, enable_roi = false, write_out = true;
+        bool do_weight = true, do_filter = true, enable_roi = false, write_out = true, json = false;
         int slabs = 1;
         std::uint32_t cycle = 0;
         int order = -1; // --order N: workgroup -> tile order of the backprojection kernels (A/B; -1 = the library's choice)
@@ -66,6 +67,7 @@ int main(int argc, char** argv)
             else if(!std::strcmp(argv[a], "--slabs") && a + 1 < argc) slabs = std::atoi(argv[++a]);
             else if(!std::strcmp(argv[a], "--cycle") && a + 1 < argc) cycle = static_cast<std::uint32_t>(std::atoi(argv[++a]));
             else if(!std::strcmp(argv[a], "--no-out")) write_out = false;
+            else if(!std::strcmp(argv[a], "--json")) json = true;
             else if(!std::strcmp(argv[a], "--order") && a + 1 < argc) order = std::atoi(argv[++a]);
             else if(!std::strcmp(argv[a], "--roi") && a + 6 < argc)
             {
@@ -123,6 +125,8 @@ int main(int argc, char** argv)
         if(write_out && out == nullptr)
             throw paris::stage_runtime_error{"cannot open " + out_path};
 
+        using clock = std::chrono::steady_clock;
+        double split_s[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // make_projection_host, frame fill, load, weight, filter, backproject, free device, free host
         double fill_s = 0.0, tail_s = 0.0; // of loop_s: the host's own frame fill (memcpy into the pinned buffer), the wait for the GPU after the last call
         double loop_s = 0.0; // the per-projection loops only (volume allocation, read-back and file output are not the hot path)
         for(int id = 0; id < info.num; ++id) // one task per slab: src/task.cpp:38-48, src/main.cpp:89-108
@@ -133,16 +137,30 @@ int main(int argc, char** argv)
             const auto t_start = std::chrono::steady_clock::now();
             for(std::uint32_t i = 0; i < n_proj; ++i)
             {
+                // every call of one iteration of src/main.cpp:98-105 between two clock reads (~20 ns each)
+                const auto c0 = clock::now();
                 auto p = paris::backend::make_projection_host(det.n_row, det.n_col);
-                const auto t_fill = std::chrono::steady_clock::now();
+                const auto c1 = clock::now();
                 std::memcpy(p.buf.get(), frames.data() + frame * (i % n_held), frame * sizeof(float));
-                fill_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fill).count();
+                const auto c2 = clock::now();
                 p.idx = i;
                 auto d_p = paris::load(p);
+                const auto c3 = clock::now();
                 if(do_weight) paris::weight(d_p, det);
+                const auto c4 = clock::now();
                 if(do_filter) paris::filter(d_p, det);
+                const auto c5 = clock::now();
                 paris::backproject(d_p, v, offset, det, vol_geo, false, enable_roi, roi);
+                const auto c6 = clock::now();
+                d_p.buf = paris::backend::projection_device_buffer_type{}; // (what the end of the reference's loop body does)
+                const auto c7 = clock::now();
+                p.buf.reset();
+                const auto c8 = clock::now();
+                const clock::time_point c[9] = {c0, c1, c2, c3, c4, c5, c6, c7, c8};
+                for(int k = 0; k < 8; ++k)
+                    split_s[k] += std::chrono::duration<double>(c[k + 1] - c[k]).count();
             }
+            fill_s = split_s[1];
             const auto t_tail = std::chrono::steady_clock::now();
             paris::backend::synchronize(); // the timed region ends when the GPU has finished, not when the last call returned
             tail_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tail).count();
@@ -164,6 +182,25 @@ int main(int argc, char** argv)
                     PARIS_HIP_BACKPROJECT_OVERLAP ? "fused launches on the second stream, uploads on the upload stream" : "one stream");
         std::printf("of which: host frame fill (memcpy into the pinned buffer) %.3f s, backend calls %.3f s, final wait for the GPU %.3f s\n", fill_s,
                     loop_s - fill_s - tail_s, tail_s);
+        {
+            const double per = 1e6 / (static_cast<double>(n_proj) * info.num);
+            std::printf("per projection [us]: make_projection_host %.2f, frame fill %.2f, load (make_projection_device + copy_h2d) %.2f, weight %.2f, filter %.2f, "
+                        "backproject %.2f, free device buffer %.2f, free host buffer %.2f\n", split_s[0] * per, split_s[1] * per, split_s[2] * per,
+                        split_s[3] * per, split_s[4] * per, split_s[5] * per, split_s[6] * per, split_s[7] * per);
+        }
+        if(json)
+        {
+            const double per = 1e6 / (static_cast<double>(n_proj) * info.num);
+            std::printf("{\"volume\": [%u, %u, %u], \"projections\": %u, \"frame\": [%u, %u], \"slabs\": %d, \"seconds\": %.6f, \"value\": %.3f, "
+                        "\"unit\": \"GVoxel-updates/s\", \"host_fill_seconds\": %.6f, \"backend_call_seconds\": %.6f, \"final_wait_seconds\": %.6f, "
+                        "\"deferral\": %d, \"streams\": \"%s\", \"filter_deferral\": %d, \"us_per_projection\": {\"make_projection_host\": %.3f, "
+                        "\"frame_fill\": %.3f, \"load\": %.3f, \"weight\": %.3f, \"filter\": %.3f, \"backproject\": %.3f, \"free_device\": %.3f, "
+                        "\"free_host\": %.3f}}\n", roi_geo.dim_x, roi_geo.dim_y, roi_geo.dim_z, n_proj, det.n_row, det.n_col, info.num, loop_s,
+                        static_cast<double>(roi_geo.dim_x) * roi_geo.dim_y * roi_geo.dim_z * n_proj / loop_s / 1e9, fill_s, loop_s - fill_s - tail_s, tail_s,
+                        PARIS_HIP_BACKPROJECT_DEFERRAL, PARIS_HIP_BACKPROJECT_OVERLAP ? "compute + second (fused launches) + upload" : "one",
+                        PARIS_HIP_FILTER_DEFERRAL, split_s[0] * per, split_s[1] * per, split_s[2] * per, split_s[3] * per, split_s[4] * per,
+                        split_s[5] * per, split_s[6] * per, split_s[7] * per);
+        }
         return 0;
     }
     catch(const paris::stage_construction_error& e)

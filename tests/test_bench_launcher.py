@@ -1,0 +1,35 @@
+"""bench.py's own launcher for N > 1, as far as a box without a GPU can show it: the placement refusal over
+nccl, and that the gloo rehearsal path starts the ranks as child processes and relays their failure (no GPU here)."""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENV = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def _gpus_visible():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_nccl_with_fewer_gpus_than_ranks_is_refused_at_once():
+    n = _gpus_visible() + 2
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "c1"], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT, env=ENV)
+    assert r.returncode == 2 and r.stdout == ""
+    assert "needs one GPU per rank" in r.stderr and "nothing was run" in r.stderr
+    assert time.perf_counter() - t0 < 120.0
+
+
+def test_launcher_relays_the_ranks_failure():
+    if _gpus_visible() > 0:
+        import pytest
+        pytest.skip("a GPU is visible: the ranks would run (tests/test_gpu_bench_contract.py covers that)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0",
+                        "--workload", "c1"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=ENV)
+    assert r.returncode != 0 and r.stdout == ""
+    assert "starting 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr and "--max-restarts 0" in r.stderr
+    assert "no GPU visible" in r.stderr  # each rank's own message: the hot path has no CPU fallback

@@ -157,6 +157,15 @@ def test_one_rank_under_torchrun_with_rccl_prints_only_the_json_line():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["rank_placement"][0]["rank"] == 0 and "final_gather" not in d
+    # the same job without the launcher gives the same figure (config 1 is launch bound: the per-launch kernel
+    # time within 10 %, the whole-step value within 25 % -- the spread of two runs on one box)
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c1", "--steps", "2", "--warmup", "1",
+                            "--cpu-budget", "0", "--cpu-c1", "0", "--fused-steps", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                           env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")})
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    q = last_json_line(plain.stdout)
+    assert abs(q["config"]["backproject_kernel_ms"] / d["config"]["backproject_kernel_ms"] - 1.0) < 0.10
+    assert abs(q["value"] / d["value"] - 1.0) < 0.25
     # the job's one collective on the nccl (= RCCL) backend, which the gloo rehearsals cannot vouch for --
     # dist.gather of the slab and all_gather_into_tensor of float64 checksums, at N = 1 (rank 0 gathers its own 64 MiB slab)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
@@ -170,6 +179,42 @@ def test_one_rank_under_torchrun_with_rccl_prints_only_the_json_line():
     assert "error" not in fg, fg
     assert fg["backend"] == "rccl" and fg["mode"] == "slabs" and fg["rccl_ranks_seen"] == 1
     assert fg["gathered_matches_checksums"] is True and len(fg["slab_checksums"]) == 1 and fg["slab_checksums"][0] != 0.0
+
+
+def test_plain_command_line_starts_its_own_ranks():
+    """`python3 bench.py --gpus N` with N > 1 and no RANK in the environment -- the way the driver calls the
+    N = 1 line -- runs the job itself: torch.distributed.run as a child process, rank 0's one JSON line relayed. Two gloo ranks on
+    the one GPU here; on a multi-GPU node the same command line runs over RCCL, one rank per GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0",
+                        "--workload", "c1", "--steps", "2", "--warmup", "1", "--fused-steps", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout  # stdout carries the one line and nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["final_gather"]["rccl_ranks_seen"] == 2
+    assert [e["rank"] for e in d["config"]["per_rank"]] == [0, 1]
+
+
+def test_plain_command_line_over_rccl_needs_a_gpu_per_rank():
+    """... and over nccl (= RCCL) with fewer GPUs than ranks it ends at once with one clear line and a non-zero status: no
+    rank is started, no two ranks silently share a card."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "needs one GPU per rank" in r.stderr and time.perf_counter() - t0 < 120.0
+    # the torchrun-started path says the same (every rank, before the rendezvous)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "need one GPU each" in r.stderr
 
 
 def test_config3_line_measures_its_traffic_in_the_run():
@@ -248,7 +293,8 @@ def test_eight_slab_partition_at_full_shape(workload, gather):
 def test_default_run_reports_every_baseline_config():
     """the driver's invocation (config 3, whole job, N = 1) ends with a `workloads` object -- config 1 and 2 as
     whole jobs, config 4's slab shape as a whole job, config 5 sampled over the circle -- each with the headline's figures, from
-    fresh child runs. (CPU legs and the live counter passes are switched off here: they have tests of their own.)"""
+    fresh child runs -- and with `paris_loop`, PARIS's per-projection loop through paris::hip for four jobs. (CPU legs and the live
+    counter passes are switched off here: they have tests of their own.)"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-budget", "0", "--cpu-c1", "0",
                         "--live-traffic", "0", "--fused-steps", "1", "--noskip-step", "0"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -267,3 +313,14 @@ def test_default_run_reports_every_baseline_config():
     assert wl["c5_sampled"]["projections_timed"] == 360 and wl["c5_sampled"]["dtype"] == "f16-in/f32"
     assert "frac_of_cache_resident_rate" in wl["c1"]["roofline"]
     assert "2048, 2048, 256" in str(wl["c4_slab_shape"]["workload"]) or "256 slices" in wl["c4_slab_shape"]["workload"]
+    # PARIS's own per-projection loop through the C++ mirror (paris_hip_demo child processes), whole circles
+    pl = d["paris_loop"]
+    assert len(pl) == 4 and any("config1" in k for k in pl) and any("2048^2" in k for k in pl)
+    for key, e in pl.items():
+        assert "error" not in e, (key, e)
+        assert e["value"] > 0 and e["seconds"] > 0 and e["unit"] == "GVoxel-updates/s" and e["deferral"] == 48
+        assert 0.0 <= e["host_fill_share"] < 1.0 and 0.0 < e["backend_call_share"] < 1.0 and "second" in e["streams"]
+        assert abs(e["value"] - float(e["volume"][0]) * e["volume"][1] * e["volume"][2] * e["projections"] / e["seconds"] / 1e9) < 1e-3 * e["value"]
+        assert sorted(e["us_per_projection"]) == ["backproject", "filter", "frame_fill", "free_device", "free_host", "load",
+                                                   "make_projection_host", "weight"]
+    assert [e["volume"] for k, e in pl.items() if "config1" in k] == [[256, 256, 256]]

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 run() { echo "== $*" >&2; "$@"; }
 # 1. counters first: bench.py's roofline.traffic and fused_extension.roofline read the newest records under profiles/
 #    (one --pmc pass each, nothing else traced); kernel times for the derived figures come from an unprofiled run
-run python bench.py --steps 8 --warmup 2 --cpu-budget 0 --cpu-c1 0 --live-traffic 0 --workloads 0 > $out/quick.json
+run python bench.py --steps 8 --warmup 2 --cpu-budget 0 --cpu-c1 0 --live-traffic 0 --workloads 0 --paris-loop 0 > $out/quick.json
 A="--steps 1 --warmup 1 --batch 16 --spread 1 --cpu-budget 0 --cpu-c1 0 --noskip-step 0 --live-traffic 0"  # 16 timed launches that sample the whole circle
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/prof_fetch -- python3 bench.py $A > /dev/null
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/prof_write -- python3 bench.py $A > /dev/null
