@@ -58,6 +58,11 @@ WORKLOADS = {
     # half after filtering and backprojected with fp32 interpolation and accumulation
     "c5": dict(n_row=2048, n_col=2048, n_proj=3600, vol=(4096, 4096, 4096), roi=(1024, 3072, 1024, 3072, 1024, 3072),
                f16=True, name="4096^3 grid, 2048^3 ROI, 3600 projections @ 2048x2048 fp16-in/fp32-accum"),
+    # the stretch variant of config 5: no ROI, the whole 4096^3 grid -- 256 GiB, so only as the slabs of a larger
+    # job: `--workload c5u --as-world 8 --as-rank-base r` is rank r's 4096 x 4096 x 512 slab (32 GiB) of the 8-GPU job
+    # (/root/reference/src/main.cpp:124-130: the ROI is optional; src/cuda/subvolume_information.cpp:72-116: the split)
+    "c5u": dict(n_row=2048, n_col=2048, n_proj=3600, vol=(4096, 4096, 4096), f16=True,
+                name="4096^3 grid un-cropped, 3600 projections @ 2048x2048 fp16-in/fp32-accum"),
 }
 
 
@@ -144,7 +149,8 @@ def live_counters(argv_tail, launches=16, fused_batch=16):
 def other_workloads(common_tail):
     """The other BASELINE configs beside the headline: fresh child runs of this script, one at a time, after the
     headline's measurements are done -- config 1 and 2 as whole jobs, config 4's slab shape (2048 x 2048 x 256, --slices 256) as a
-    whole job, config 5 sampled over the circle (360 of its 3600 launches) -- each reduced to the figures the headline reports for
+    whole job, config 5 sampled over the circle (360 of its 3600 launches), and one rank's slab of config 5 WITHOUT the ROI crop
+    (4096 x 4096 x 512 of the 4096^3 grid, 72 launches over the circle) -- each reduced to the figures the headline reports for
     config 3. Children are ordinary child processes of this one (which keeps its GPU context: two processes on the card)."""
     import subprocess
     env = dict(os.environ)
@@ -155,6 +161,9 @@ def other_workloads(common_tail):
         ("c2", ["--workload", "c2", "--steps", "10", "--warmup", "2"]),
         ("c4_slab_shape", ["--workload", "c3", "--slices", "256", "--steps", "20", "--warmup", "2"]),
         ("c5_sampled", ["--workload", "c5", "--steps", "10", "--warmup", "1", "--batch", "36", "--spread", "1"]),
+        # config 5 without the ROI crop: rank 3's 4096 x 4096 x 512 slab of the 8-GPU job over the whole 4096^3 grid, sampled
+        ("c5_uncropped_slab", ["--workload", "c5u", "--as-world", "8", "--as-rank-base", "3", "--steps", "4", "--warmup", "1", "--batch", "18",
+                               "--spread", "1", "--fused-steps", "4"]),
     ]
     out = {}
     for name, argv in plans:
@@ -173,7 +182,7 @@ def other_workloads(common_tail):
             continue
         rf, cfg = d["roofline"], d["config"]
         e = {"workload": cfg["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
-             "projections_timed": cfg["projections_timed"], "whole_job": cfg["whole_job"], "dtype": d["dtype"],
+             "projections_timed": cfg["projections_timed"], "whole_job": cfg["whole_job"], "dtype": d["dtype"], "slab": cfg["slab_per_gpu"],
              "backproject_kernel_ms": cfg["backproject_kernel_ms"],
              "roofline": {"bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "unit": rf["unit"],
                           "frac_without_skip": rf.get("frac_without_skip"), "launches_timed": rf["launches_timed"]},

@@ -301,7 +301,7 @@ def test_default_run_reports_every_baseline_config():
     d = last_json_line(r.stdout)
     assert d["config"]["whole_job"] is True and d["config"]["projections_timed"] == 1440
     wl = d["workloads"]
-    assert sorted(wl) == ["c1", "c2", "c4_slab_shape", "c5_sampled"]
+    assert sorted(wl) == ["c1", "c2", "c4_slab_shape", "c5_sampled", "c5_uncropped_slab"]
     for name, e in wl.items():
         assert "error" not in e, (name, e)
         for key in ("value", "backproject_kernel_ms", "fused", "deferred", "ms_per_step", "projections_timed", "whole_job"):
@@ -311,6 +311,9 @@ def test_default_run_reports_every_baseline_config():
     assert wl["c1"]["whole_job"] and wl["c2"]["whole_job"] and wl["c4_slab_shape"]["whole_job"] and not wl["c5_sampled"]["whole_job"]
     assert wl["c1"]["projections_timed"] == 360 and wl["c2"]["projections_timed"] == 720 and wl["c4_slab_shape"]["projections_timed"] == 1440
     assert wl["c5_sampled"]["projections_timed"] == 360 and wl["c5_sampled"]["dtype"] == "f16-in/f32"
+    # one rank's slab of config 5 without the ROI crop -- 4096 x 4096 x 512 of the 4096^3 grid, 32 GiB
+    cu = wl["c5_uncropped_slab"]
+    assert cu["slab"] == [4096, 4096, 512] and cu["dtype"] == "f16-in/f32" and cu["projections_timed"] == 72 and not cu["whole_job"]
     assert "frac_of_cache_resident_rate" in wl["c1"]["roofline"]
     assert "2048, 2048, 256" in str(wl["c4_slab_shape"]["workload"]) or "256 slices" in wl["c4_slab_shape"]["workload"]
     # PARIS's own per-projection loop through the C++ mirror (paris_hip_demo child processes), whole circles
