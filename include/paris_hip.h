@@ -315,7 +315,27 @@ int paris_hip_backproject_batch_f16(paris_hip_ctx* ctx, const uint16_t* d_p, siz
  * default) is immediate execution. The C++ mirror paris::hip enables depth 48, so PARIS's unchanged per-projection loop
  * (src/main.cpp:98-105) runs at the fused kernel's rate. */
 int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t depth);
+/* (The first groups of a sequence of calls into one volume are launched early -- after 8, 16 and 32 calls, then every `depth` -- so
+ * that the device starts while the caller is still feeding the first full group; a call with other arguments, or a change of the
+ * depth, starts a new sequence.) */
 int paris_hip_flush(paris_hip_ctx* ctx);
+/* Extension: deferral BY REFERENCE. With enable != 0 a deferred paris_hip_backproject[_f16] whose projection is a whole buffer of
+ * paris_hip_malloc_projection (the pointer it returned, its pitch) takes NO snapshot: the group's fused launch reads the buffer
+ * itself. The library answers for such a buffer until that launch has been made: paris_hip_free of it returns at once and the
+ * buffer goes back to the pool behind the launch (one event per group instead of one per buffer, no copy enqueued per call); any
+ * other entry point that reads or writes the buffer -- a second weighting or filter, an upload into it, a copy to the host --
+ * launches the pending group first, so every result is what the snapshot would have given, bit for bit. With filter deferral
+ * the held-back weight + filter of such a projection runs IN PLACE in the group's one filter launch: the buffer holds the filtered
+ * pixels whenever anything looks at it through this API. The one thing the library cannot see is work the caller enqueues on
+ * the ctx stream by itself: a caller whose own kernels write projection buffers after backprojecting them leaves this off (the
+ * default; snapshots). Projections in memory the library did not allocate, row-band pointers into a buffer and other pitches
+ * are snapshotted as before (a group may mix both). paris::hip switches it on: PARIS's loop (src/main.cpp:98-105) allocates,
+ * fills, backprojects and frees one buffer per projection (src/loader.cpp:28-33) and touches nothing outside the backend. */
+int paris_hip_set_backproject_references(paris_hip_ctx* ctx, int enable);
+/* What this ctx may keep allocated for projections of dim_x x dim_y pixels beside the volume, with its present deferral settings (the
+ * rotation of paris_hip_malloc_projection buffers, the pending group's buffers or the snapshot ring): the reserve_bytes a driver
+ * passes to paris_hip_make_subvolume_information_reserving. */
+int paris_hip_projection_reserve_bytes(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, size_t* bytes);
 /* How many projections are pending right now and into which volume (NULL when none): what a wrapper that lends the library memory
  * it does not own needs to decide whether a last paris_hip_flush is still safe (paris_amd.backend.Backend.close). */
 int paris_hip_pending_backprojections(paris_hip_ctx* ctx, uint32_t* count, void** d_v);
@@ -326,11 +346,22 @@ int paris_hip_pending_backprojections(paris_hip_ctx* ctx, uint32_t* count, void*
  * its snapshots, one launch for the whole group, right before the group's fused backprojection: the volume is bit-identical. Any
  * other entry point runs the held-back launch first, in place, as if it had never been held. The one thing that changes: after
  * such a backprojection the caller's projection buffer still holds the UNFILTERED pixels (PARIS's loop, src/main.cpp:98-105,
- * never looks at a projection again after backprojecting it; a caller that does leaves this off). Off by default, also in the C++
- * mirror paris::hip (macro PARIS_HIP_FILTER_DEFERRAL): it pays where the GPU's small launches are the limit (bench.py's deferred
- * leg at config 1: 706 -> 913 GVox/s), little where the host loop is as well (PARIS's own per-projection allocate / fill / upload:
- * +3 % at 512^2, nothing at 1024^2). */
+ * never looks at a projection again after backprojecting it; a caller that does leaves this off). Off by default in the bare
+ * library. enable == 2 holds a filter back ONLY where nobody can tell: with deferral by reference on
+ * (paris_hip_set_backproject_references) and a projection that is a whole buffer of paris_hip_malloc_projection -- the filter then
+ * runs IN PLACE in the group's one filter launch and every other call that touches the buffer runs it first, so the buffer holds
+ * the filtered pixels whenever anything looks at it through this API; everything else is filtered at once. That is what the C++
+ * mirror paris::hip switches on (macro PARIS_HIP_FILTER_DEFERRAL = 2): one filter launch per group instead of one per projection
+ * (config 1 through PARIS's loop: profiles/r05_demo_paris_hip_mirror.txt). */
 int paris_hip_set_filter_deferral(paris_hip_ctx* ctx, int enable);
+/* Extension: asynchronous validation. The hand-expanded IEEE sequences (fast division by the pixel pitch, shared-reciprocal
+ * divisions, short sqrt / divide of the weighting) are used only after a device validator has proved them for the operands at hand,
+ * once per process, device and operand range; by default the call that needs an answer first waits for the validator (2.3 ms for
+ * the exhaustive check of a pixel pitch). With enable != 0 that call launches the validator on the ctx's auxiliary stream and
+ * goes on with the compiler's IEEE forms -- the same bits, a few instructions more per voxel column -- until a later call finds
+ * the answer there. Results never depend on it; paris_hip_fast_division_is_exact and the paris_hip_lean_*_is_exact queries always
+ * wait. Off by default in the bare library (which kernel form a given launch uses then depends on timing), on in paris::hip. */
+int paris_hip_set_async_validation(paris_hip_ctx* ctx, int enable);
 /* Where the fused launch of a full group runs: with enable != 0 on a second stream of the ctx, ordered behind the
  * group's snapshot copies, so that the uploads, weightings and filters of the NEXT group -- which the caller keeps enqueuing on
  * the ctx stream -- execute beside it instead of behind it (what small volumes need: a 256^3 launch of 16 projections takes about

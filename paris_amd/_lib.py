@@ -127,6 +127,9 @@ SIGNATURES = {
     "paris_hip_set_lean_validation": (C.c_int, [_vp, C.c_int]),
     "paris_hip_pending_backprojections": (C.c_int, [_vp, _P(_u32), _P(C.c_void_p)]),
     "paris_hip_set_backproject_overlap": (C.c_int, [_vp, C.c_int]),
+    "paris_hip_set_backproject_references": (C.c_int, [_vp, C.c_int]),
+    "paris_hip_set_async_validation": (C.c_int, [_vp, C.c_int]),
+    "paris_hip_projection_reserve_bytes": (C.c_int, [_vp, _u32, _u32, _P(_sz)]),
     "paris_hip_slab_row_band": (C.c_int, [_P(DetectorGeometry), _P(VolumeGeometry), _u32, _u32, _u32, _u32, C.c_int,
                                           _P(RegionOfInterest), _P(_u32), _P(_u32)]),
     "paris_hip_stage_angle": (C.c_int, [_P(DetectorGeometry), _u32, C.c_int, _f, _P(_f), _P(_f)]),

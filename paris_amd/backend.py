@@ -389,7 +389,7 @@ class Backend:
         """paris_hip_set_filter_deferral: with stage fusion and a deferral depth > 1, the filter() that follows a weight() is held back
         too and runs on the library's snapshot, a group per launch, if the next call backprojects that projection (whose buffer then
         keeps its unfiltered pixels); bit-identical volume"""
-        check(self._L.paris_hip_set_filter_deferral(self._ctx, int(bool(enable))), "paris_hip_set_filter_deferral")
+        check(self._L.paris_hip_set_filter_deferral(self._ctx, 2 if enable == 2 else int(bool(enable))), "paris_hip_set_filter_deferral")
 
     def set_backproject_deferral(self, depth):
         """depth > 1: backproject() calls are snapshotted and added by one fused launch per `depth` calls (bit-identical)"""
@@ -398,6 +398,23 @@ class Backend:
     def set_backproject_overlap(self, enable=True):
         """deferred fused launches run on a second stream beside the caller's next calls (default off: measured slower)"""
         check(self._L.paris_hip_set_backproject_overlap(self._ctx, int(bool(enable))), "paris_hip_set_backproject_overlap")
+
+    def set_backproject_references(self, enable=True):
+        """deferral by reference: a deferred backproject() of a whole make_projection_device buffer takes no snapshot, the group's
+        fused launch reads the buffer itself; free() of it returns at once and the buffer is recycled behind the launch; any other
+        call that touches it launches the pending group first (bit-identical; paris::hip switches it on)"""
+        check(self._L.paris_hip_set_backproject_references(self._ctx, int(bool(enable))), "paris_hip_set_backproject_references")
+
+    def set_async_validation(self, enable=True):
+        """validators of the hand-expanded IEEE sequences are launched and not waited for; the compiler's forms serve until they
+        have answered (same bits)"""
+        check(self._L.paris_hip_set_async_validation(self._ctx, int(bool(enable))), "paris_hip_set_async_validation")
+
+    def projection_reserve_bytes(self, dim_x, dim_y):
+        """what this ctx may keep allocated for projections of that size beside the volume (buffer rotation, pending group or ring)"""
+        n = C.c_size_t(0)
+        check(self._L.paris_hip_projection_reserve_bytes(self._ctx, dim_x, dim_y, C.byref(n)), "paris_hip_projection_reserve_bytes")
+        return int(n.value)
 
     def flush(self):
         check(self._L.paris_hip_flush(self._ctx), "paris_hip_flush")

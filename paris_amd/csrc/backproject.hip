@@ -474,20 +474,10 @@ namespace
     std::mutex fastdiv_mutex;
     std::map<std::pair<int, uint32_t>, bool> fastdiv_cache; // (device, divisor bits) -> exhaustive check result
 
-    int fastdiv_check_on_device(paris_hip_ctx* ctx, float c, bool* ok)
+    void fastdiv_enqueue(hipStream_t s, unsigned long long* counter, const void* arg)
     {
-        *ok = false;
-        if(int rc = paris_hip_ensure_aux(ctx))
-            return rc;
-        hipStream_t s = ctx->aux_stream;
-        unsigned long long bad = ~0ull;
-        PARIS_HIP_TRY(hipMemsetAsync(ctx->aux_counter, 0, sizeof(bad), s));
-        hipLaunchKernelGGL(fastdiv_validate_kernel, dim3(1u << 16), dim3(256), 0, s, c, 1.f / c, ctx->aux_counter);
-        PARIS_HIP_TRY(hipGetLastError());
-        PARIS_HIP_TRY(hipMemcpyAsync(&bad, ctx->aux_counter, sizeof(bad), hipMemcpyDeviceToHost, s)); // pageable destination: staged by the runtime
-        PARIS_HIP_TRY(hipStreamSynchronize(s));
-        *ok = bad == 0ull;
-        return PARIS_HIP_SUCCESS;
+        const float c = *static_cast<const float*>(arg);
+        hipLaunchKernelGGL(fastdiv_validate_kernel, dim3(1u << 16), dim3(256), 0, s, c, 1.f / c, counter);
     }
 
     int fastdiv_is_exact(paris_hip_ctx* ctx, float c, bool* ok)
@@ -506,9 +496,11 @@ namespace
             auto pit = fastdiv_cache.find(pkey);
             if(pit == fastdiv_cache.end())
             {
-                bool exact = false;
-                if(int rc = fastdiv_check_on_device(ctx, c, &exact))
+                bool exact = false, known = false;
+                if(int rc = paris_hip_run_check(ctx, {2u, key, 0u, 0u}, fastdiv_enqueue, &c, &exact, &known))
                     return rc;
+                if(!known) // asynchronous validation: the check is running; the IEEE division serves until it has answered
+                    return PARIS_HIP_SUCCESS;
                 pit = fastdiv_cache.emplace(pkey, exact).first;
             }
             it = ctx->fastdiv_exact.emplace(key, pit->second).first;
@@ -721,10 +713,10 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         PARIS_HIP_TRY(hipEventRecord(ctx->bp_start[ev], ctx->stream));
     if(ctx->bp_variant == 4 && !f16) // the fused kernel with a single projection (measurement: all slices of a tile in flight)
     {
-        FusedParams fp;
+        FusedParams fp{};
         fp.g = g;
         fp.n_proj = 1;
-        fp.proj_stride = 0;
+        fp.proj_tab[0] = d_p;
         fp.sin_phi[0] = sin_phi;
         fp.cos_phi[0] = cos_phi;
         const int width = lane_width(d_v, v_dim_x);
@@ -822,7 +814,8 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
 static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, size_t p_stride_bytes, uint32_t n_proj, uint32_t p_dim_x,
                       uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
                       const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
-                      const paris_region_of_interest* roi, const float* sin_phi, const float* cos_phi, float delta_s, float delta_t);
+                      const paris_region_of_interest* roi, const float* sin_phi, const float* cos_phi, float delta_s, float delta_t,
+                      const void* const* ptrs = nullptr);
 
 int paris_hip_launch_deferred(paris_hip_ctx* ctx)
 {
@@ -834,7 +827,9 @@ int paris_hip_launch_deferred(paris_hip_ctx* ctx)
     const uint32_t n = ctx->defer_count;
     const uint32_t depth = ctx->defer_depth;
     const uint32_t half = ctx->defer_half;
-    const char* ring = reinterpret_cast<const char*>(ctx->defer_ring) + static_cast<size_t>(half) * ctx->defer_slots * ctx->defer_pitch * ctx->defer_dim_y;
+    const bool has_refs = ctx->held_count != 0u || !ctx->defer_zombies.empty();
+    // slot i of the group lives at defer_ptr[i]: a snapshot in this half of the ring, or the caller's own buffer (by reference)
+    const void* const* where = ctx->defer_ptr.data();
     // beside the caller's next calls, on the ctx's second stream -- unless the caller wants every call complete on return, or is
     // capturing `stream` into a graph (a fork it does not know of would leave the capture unjoined)
     bool overlap = ctx->bp_overlap != 0 && n > 1 && !(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS);
@@ -880,15 +875,20 @@ int paris_hip_launch_deferred(paris_hip_ctx* ctx)
                       && std::memcmp(&w.h_min, &w0.h_min, 5u * sizeof(float)) == 0 && w.d_kp == w0.d_kp && w.plan == w0.plan
                       && w.filter_size == w0.filter_size;
         }
-        const size_t slot_bytes = ctx->defer_pitch * ctx->defer_dim_y;
         const uint32_t pitch_f = static_cast<uint32_t>(ctx->defer_pitch / sizeof(float));
+        const auto rows_of = [&](uint32_t i, uint32_t row_first) {
+            return reinterpret_cast<float*>(static_cast<char*>(const_cast<void*>(where[i])) + static_cast<size_t>(row_first) * ctx->defer_pitch);
+        };
         int wrc = PARIS_HIP_SUCCESS;
         if(flagged == n && uniform && n > 0)
         {
+            // one launch for the group: the frames' band rows by table (snapshots in the ring and buffers by reference alike)
             const auto& w = ctx->defer_wf[0];
-            float* rows = reinterpret_cast<float*>(const_cast<char*>(ring) + static_cast<size_t>(w.row_first) * ctx->defer_pitch);
-            wrc = paris_hip_fused_filter_launch(ctx, rows, pitch_f, w.dim_x, w.row_count, w.row_first, true, w.h_min, w.v_min, w.d_sd, w.l_px_row,
-                                                w.l_px_col, w.d_kp, w.plan, w.filter_size, nullptr, 0u, n, static_cast<uint32_t>(slot_bytes / sizeof(float)), 0u);
+            float* tab[FUSED_MAX];
+            for(uint32_t i = 0; i < n; ++i)
+                tab[i] = rows_of(i, w.row_first);
+            wrc = paris_hip_fused_filter_launch(ctx, tab[0], pitch_f, w.dim_x, w.row_count, w.row_first, true, w.h_min, w.v_min, w.d_sd, w.l_px_row,
+                                                w.l_px_col, w.d_kp, w.plan, w.filter_size, nullptr, 0u, n, 0u, 0u, tab);
         }
         else
             for(uint32_t i = 0; i < n && i < ctx->defer_wf.size() && wrc == PARIS_HIP_SUCCESS; ++i)
@@ -896,37 +896,73 @@ int paris_hip_launch_deferred(paris_hip_ctx* ctx)
                 const auto& w = ctx->defer_wf[i];
                 if(!w.active)
                     continue;
-                float* rows = reinterpret_cast<float*>(const_cast<char*>(ring) + i * slot_bytes + static_cast<size_t>(w.row_first) * ctx->defer_pitch);
-                wrc = paris_hip_fused_filter_launch(ctx, rows, pitch_f, w.dim_x, w.row_count, w.row_first, true, w.h_min, w.v_min, w.d_sd, w.l_px_row,
-                                                    w.l_px_col, w.d_kp, w.plan, w.filter_size, nullptr, 0u);
+                wrc = paris_hip_fused_filter_launch(ctx, rows_of(i, w.row_first), pitch_f, w.dim_x, w.row_count, w.row_first, true, w.h_min, w.v_min, w.d_sd,
+                                                    w.l_px_row, w.l_px_col, w.d_kp, w.plan, w.filter_size, nullptr, 0u);
             }
         for(auto& w : ctx->defer_wf)
             w.active = false;
         if(wrc != PARIS_HIP_SUCCESS)
         {
-            // the group's snapshots are unfiltered and stay so: the group is dropped rather than added to the volume as it is by
+            // the group's projections are unfiltered and stay so: the group is dropped rather than added to the volume as it is by
             // the next flush; the caller sees the error
             ctx->defer_count = 0;
+            ctx->defer_uses_ring = false;
             ctx->stream = caller_stream;
+            (void)paris_hip_release_group_references(ctx, 0u);
             return wrc;
         }
     }
     ctx->defer_count = 0; // before the launch: batch_impl may fall back to single launches, which must not be deferred again
     ctx->defer_depth = 1;
-    const int rc = batch_impl(ctx, ring, ctx->defer_f16, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
-                              ctx->defer_dim_y, ctx->key_v, ctx->key_dims[0], ctx->key_dims[1], ctx->key_dims[2], ctx->key_dims[3],
-                              &ctx->key_det, &ctx->key_vol, ctx->key_enable_roi, &ctx->key_roi, ctx->defer_sin.data(),
-                              ctx->defer_cos.data(), ctx->key_delta_s, ctx->key_delta_t);
+    // (held_count is parked while the launch is made: the projections it reads are the group's own, nothing to guard against)
+    const uint32_t held = ctx->held_count;
+    ctx->held_count = 0u;
+    int rc = batch_impl(ctx, where[0], ctx->defer_f16, ctx->defer_pitch, ctx->defer_pitch * ctx->defer_dim_y, n, ctx->defer_dim_x,
+                        ctx->defer_dim_y, ctx->key_v, ctx->key_dims[0], ctx->key_dims[1], ctx->key_dims[2], ctx->key_dims[3],
+                        &ctx->key_det, &ctx->key_vol, ctx->key_enable_roi, &ctx->key_roi, ctx->defer_sin.data(),
+                        ctx->defer_cos.data(), ctx->key_delta_s, ctx->key_delta_t, where);
+    ctx->held_count = held;
+    hipStream_t ran_on = ctx->stream;
     ctx->stream = caller_stream;
     ctx->defer_depth = depth;
+    if(has_refs)
+    {
+        // ONE event for every buffer the group read by reference: recorded behind the launch on the stream that ran it
+        uint64_t group = 0u;
+        if(rc == PARIS_HIP_SUCCESS)
+        {
+            group = ctx->group_seq + 1u;
+            hipEvent_t& e = ctx->group_events[group % paris_hip_ctx::GROUP_EVENTS];
+            hipError_t err = e != nullptr ? hipSuccess : hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if(err == hipSuccess)
+                err = hipEventRecord(e, ran_on);
+            if(err != hipSuccess)
+            {
+                // no event to wait for later: wait now (the buffers are then free at once)
+                (void)hipStreamSynchronize(ran_on);
+                group = 0u;
+                rc = static_cast<int>(err);
+            }
+            else
+                ctx->group_seq = group;
+        }
+        else
+            (void)hipStreamSynchronize(ran_on); // whatever part of the group was launched has read its buffers
+        const int rrc = paris_hip_release_group_references(ctx, group);
+        if(rc == PARIS_HIP_SUCCESS)
+            rc = rrc;
+    }
     if(overlap)
     {
         PARIS_HIP_TRY(hipEventRecord(ctx->bp_half_done[half], ctx->bp_stream));
-        ctx->bp_half_busy[half] = true;
+        if(ctx->defer_uses_ring) // (a group of references leaves its half of the ring alone)
+            ctx->bp_half_busy[half] = true;
         ctx->bp_inflight = true;
         ctx->bp_last_half = half;
     }
-    ctx->defer_half = half ^ 1u;
+    if(ctx->defer_uses_ring)
+        ctx->defer_half = half ^ 1u;
+    ctx->defer_uses_ring = false;
     return rc;
 }
 
@@ -990,36 +1026,27 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
                       && ctx->key_enable_roi == (enable_roi ? 1 : 0) && std::memcmp(&ctx->key_roi, &r, sizeof(r)) == 0
                       && std::memcmp(&ctx->key_delta_s, &delta_s, sizeof(float)) == 0 && std::memcmp(&ctx->key_delta_t, &delta_t, sizeof(float)) == 0
                       && ctx->defer_dim_x == p_dim_x && ctx->defer_dim_y == p_dim_y && ctx->defer_f16 == f16
-                      && ctx->defer_ring != nullptr && ctx->defer_slots >= ctx->defer_depth;
+                      && ctx->defer_ptr.size() >= ctx->defer_depth;
     if(!same)
     {
         if(int rc = paris_hip_flush_deferred(ctx))
             return give_back(rc);
         ctx->key_valid = false;
-        if(ctx->defer_dim_x != p_dim_x || ctx->defer_dim_y != p_dim_y || ctx->defer_slots < ctx->defer_depth || ctx->defer_f16 != f16 || ctx->defer_ring == nullptr)
+        if(ctx->defer_ring != nullptr && (ctx->defer_dim_x != p_dim_x || ctx->defer_dim_y != p_dim_y || ctx->defer_slots < ctx->defer_depth || ctx->defer_f16 != f16))
         {
-            if(ctx->defer_ring != nullptr)
-            {
-                hipError_t err = hipStreamSynchronize(ctx->stream); // a launch may still read the old ring (the flush above joined the second stream)
-                if(err == hipSuccess)
-                    err = hipFree(ctx->defer_ring);
-                if(err != hipSuccess)
-                    return give_back(static_cast<int>(err));
-                ctx->defer_ring = nullptr;
-                ctx->defer_slots = 0;
-            }
-            ctx->defer_pitch = (static_cast<size_t>(p_dim_x) * px + 255u) / 256u * 256u;
-            ctx->defer_f16 = f16;
-            const hipError_t err = hipMalloc(reinterpret_cast<void**>(&ctx->defer_ring), 2u * ctx->defer_pitch * p_dim_y * ctx->defer_depth); // two halves
+            // the ring is of another shape: a new one is made when a snapshot needs it
+            hipError_t err = hipStreamSynchronize(ctx->stream); // a launch may still read the old ring (the flush above joined the second stream)
+            if(err == hipSuccess)
+                err = hipFree(ctx->defer_ring);
             if(err != hipSuccess)
-            {
-                ctx->defer_ring = nullptr;
                 return give_back(static_cast<int>(err));
-            }
-            ctx->defer_dim_x = p_dim_x;
-            ctx->defer_dim_y = p_dim_y;
-            ctx->defer_slots = ctx->defer_depth;
+            ctx->defer_ring = nullptr;
+            ctx->defer_slots = 0;
         }
+        ctx->defer_pitch = (static_cast<size_t>(p_dim_x) * px + 255u) / 256u * 256u;
+        ctx->defer_f16 = f16;
+        ctx->defer_dim_x = p_dim_x;
+        ctx->defer_dim_y = p_dim_y;
         ctx->key_v = d_v;
         std::memcpy(ctx->key_dims, dims, sizeof(dims));
         ctx->key_det = *det_geo;
@@ -1032,19 +1059,56 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
         ctx->defer_ramp = 8u; // a new sequence: its first groups are launched early
         ctx->defer_sin.assign(ctx->defer_depth, 0.f);
         ctx->defer_cos.assign(ctx->defer_depth, 0.f);
+        ctx->defer_ptr.assign(ctx->defer_depth, nullptr);
         ctx->defer_wf.assign(ctx->defer_depth, paris_hip_ctx::pending_weight_t{});
     }
-    const uint32_t half = ctx->defer_half;
-    if(ctx->defer_count == 0 && ctx->bp_half_busy[half])
+    // By reference (paris_hip_set_backproject_references): the projection is a whole buffer of paris_hip_malloc_projection with the
+    // ring's row pitch -- the group reads the buffer itself. Until the group has been launched the library answers for the buffer:
+    // paris_hip_free() marks it, every other call that touches it launches the group first (paris_hip_projection_guard).
+    paris_hip_ctx::proj_alloc* mine = nullptr;
+    if(ctx->defer_refs != 0 && p_pitch == ctx->defer_pitch && !(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS))
     {
-        // the fused launch that read this half of the ring (two groups ago) must be done before the half is written again
-        const hipError_t err = hipStreamWaitEvent(ctx->stream, ctx->bp_half_done[half], 0);
-        if(err != hipSuccess)
-            return give_back(static_cast<int>(err));
-        ctx->bp_half_busy[half] = false;
+        auto a = ctx->proj_allocs.find(const_cast<void*>(d_p));
+        if(a != ctx->proj_allocs.end() && a->second.bytes >= p_pitch * static_cast<size_t>(p_dim_y))
+            mine = &a->second;
     }
-    char* slot = reinterpret_cast<char*>(ctx->defer_ring) + ctx->defer_pitch * p_dim_y * (static_cast<size_t>(half) * ctx->defer_slots + ctx->defer_count);
+    const void* lives_at = d_p;
+    if(mine != nullptr)
     {
+        ++mine->held;
+        ++ctx->held_count;
+        mine->touched = true;
+    }
+    else
+    {
+        if(ctx->defer_ring == nullptr)
+        {
+            hipError_t err = hipMalloc(reinterpret_cast<void**>(&ctx->defer_ring), 2u * ctx->defer_pitch * p_dim_y * ctx->defer_depth); // two halves
+            if(err == hipErrorOutOfMemory)
+            {
+                (void)hipGetLastError();
+                if(int rc = paris_hip_drain_device_pool(ctx))
+                    return give_back(rc);
+                err = hipMalloc(reinterpret_cast<void**>(&ctx->defer_ring), 2u * ctx->defer_pitch * p_dim_y * ctx->defer_depth);
+            }
+            if(err != hipSuccess)
+            {
+                ctx->defer_ring = nullptr;
+                return give_back(static_cast<int>(err));
+            }
+            ctx->defer_slots = ctx->defer_depth;
+        }
+        const uint32_t half = ctx->defer_half;
+        if(!ctx->defer_uses_ring && ctx->bp_half_busy[half])
+        {
+            // the fused launch that read this half of the ring (two ring groups ago) must be done before the half is written again
+            const hipError_t err = hipStreamWaitEvent(ctx->stream, ctx->bp_half_done[half], 0);
+            if(err != hipSuccess)
+                return give_back(static_cast<int>(err));
+            ctx->bp_half_busy[half] = false;
+        }
+        ctx->defer_uses_ring = true;
+        char* slot = reinterpret_cast<char*>(ctx->defer_ring) + ctx->defer_pitch * p_dim_y * (static_cast<size_t>(half) * ctx->defer_slots + ctx->defer_count);
         hipError_t err = hipSuccess;
         if(p_pitch == ctx->defer_pitch) // rows as far apart as the ring's: one linear copy (the padding travels along)
             err = hipMemcpyAsync(slot, d_p, p_pitch * (p_dim_y - 1u) + static_cast<size_t>(p_dim_x) * px, hipMemcpyDeviceToDevice, ctx->stream);
@@ -1052,9 +1116,13 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
             err = hipMemcpy2DAsync(slot, ctx->defer_pitch, d_p, p_pitch, static_cast<size_t>(p_dim_x) * px, p_dim_y, hipMemcpyDeviceToDevice, ctx->stream);
         if(err != hipSuccess)
             return give_back(static_cast<int>(err));
+        if(int rc = paris_hip_note_projection_use(ctx, d_p, p_pitch * p_dim_y)) // the snapshot copy is the last reader of the caller's buffer
+            return give_back(rc);
+        lives_at = slot;
     }
-    if(int rc = paris_hip_note_projection_use(ctx, d_p, p_pitch * p_dim_y)) // the snapshot copy is the last reader of the caller's buffer
-        return give_back(rc);
+    if(ctx->defer_ptr.size() < ctx->defer_depth)
+        ctx->defer_ptr.resize(ctx->defer_depth, nullptr);
+    ctx->defer_ptr[ctx->defer_count] = lives_at;
     ctx->defer_sin[ctx->defer_count] = sin_phi;
     ctx->defer_cos[ctx->defer_count] = cos_phi;
     if(ctx->defer_wf.size() < ctx->defer_depth)
@@ -1078,6 +1146,68 @@ extern "C" int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t d
     if(int rc = paris_hip_flush_deferred(ctx))
         return rc;
     ctx->defer_depth = depth;
+    // a sequence continued after this call starts over: its tables are sized for the new depth and its first groups are launched
+    // early again
+    ctx->key_valid = false;
+    ctx->defer_ramp = 8u;
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_set_backproject_references(paris_hip_ctx* ctx, int enable)
+{
+    if(ctx == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(int rc = paris_hip_flush_deferred(ctx))
+        return rc;
+    ctx->defer_refs = enable ? 1 : 0;
+    return PARIS_HIP_SUCCESS;
+}
+
+// What this ctx may keep allocated for projections of dim_x x dim_y pixels beside the caller's volume, with its present deferral
+// settings: the buffer rotation of paris_hip_malloc_projection (parked buffers), the pending group's buffers or the ring of
+// snapshots. A driver passes it to paris_hip_make_subvolume_information_reserving.
+extern "C" int paris_hip_projection_reserve_bytes(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, size_t* bytes)
+{
+    if(ctx == nullptr || bytes == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    const size_t frame = ((static_cast<size_t>(dim_x) * sizeof(float) + 255u) & ~static_cast<size_t>(255u)) * dim_y;
+    size_t total = std::min(ctx->device_pool_capacity(frame) * frame, paris_hip_ctx::PARKED_DEVICE_LIMIT + frame);
+    if(ctx->defer_depth > 1u)
+        total += (ctx->defer_refs != 0 ? 1u : 2u) * static_cast<size_t>(ctx->defer_depth) * frame; // the pending group by reference, or the ring's two halves
+    *bytes = total;
+    return PARIS_HIP_SUCCESS;
+}
+
+int paris_hip_projection_guard_slow(paris_hip_ctx* ctx, const void* d_p, size_t bytes, hipStream_t writer, bool writes)
+{
+    (void)bytes; // (a call's range lies inside one allocation: the one that holds its first byte)
+    if(d_p == nullptr || ctx->proj_allocs.empty())
+        return PARIS_HIP_SUCCESS;
+    auto a = ctx->proj_allocs.upper_bound(const_cast<void*>(d_p));
+    if(a == ctx->proj_allocs.begin())
+        return PARIS_HIP_SUCCESS;
+    --a;
+    if(static_cast<const char*>(d_p) >= static_cast<const char*>(a->first) + a->second.bytes)
+        return PARIS_HIP_SUCCESS;
+    if(a->second.held != 0u)
+    {
+        // the pending group reads this buffer itself (and may still have its weight + filter to run in it): the group goes first
+        if(int rc = paris_hip_launch_deferred(ctx))
+            return rc;
+    }
+    (void)writes;
+    // a launched group may still be reading the buffer -- or, with filter deferral, still be filtering it in place: a write waits for
+    // that launch, and so does a read (it must see the filtered pixels)
+    if(a->second.group != 0u)
+    {
+        bool done = false;
+        if(int rc = paris_hip_group_done(ctx, a->second.group, false, &done))
+            return rc;
+        if(done)
+            a->second.group = 0u;
+        else // (the event of that launch, or of a later one recorded in the same slot)
+            PARIS_HIP_TRY(hipStreamWaitEvent(writer != nullptr ? writer : ctx->stream, ctx->group_events[a->second.group % paris_hip_ctx::GROUP_EVENTS], 0));
+    }
     return PARIS_HIP_SUCCESS;
 }
 
@@ -1171,10 +1301,16 @@ extern "C" int paris_hip_convert_projection_f16(paris_hip_ctx* ctx, const float*
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(dim_x == 0 || dim_y == 0)
         return paris_hip_finish(ctx);
+    if(int rc = paris_hip_projection_guard(ctx, d_src, src_pitch * dim_y, nullptr, false))
+        return rc;
+    if(int rc = paris_hip_projection_guard(ctx, d_dst, dst_pitch * dim_y, ctx->stream, true))
+        return rc;
     const dim3 grid((dim_x + 255u) / 256u, dim_y < 65535u ? dim_y : 65535u);
     hipLaunchKernelGGL(to_half_kernel, grid, dim3(256), 0, ctx->stream, d_src, static_cast<uint32_t>(src_pitch / sizeof(float)),
                        reinterpret_cast<_Float16*>(d_dst), static_cast<uint32_t>(dst_pitch / sizeof(uint16_t)), dim_x, dim_y);
     if(int rc = paris_hip_note_projection_use(ctx, d_src, src_pitch * dim_y))
+        return rc;
+    if(int rc = paris_hip_note_projection_use(ctx, d_dst, dst_pitch * dim_y)) // (the destination is written by this launch)
         return rc;
     return paris_hip_finish(ctx);
 }
@@ -1210,17 +1346,19 @@ extern "C" int paris_hip_backproject_batch_f16(paris_hip_ctx* ctx, const uint16_
 static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, size_t p_stride_bytes, uint32_t n_proj, uint32_t p_dim_x,
                       uint32_t p_dim_y, float* d_v, uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
                       const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
-                      const paris_region_of_interest* roi, const float* sin_phi, const float* cos_phi, float delta_s, float delta_t)
+                      const paris_region_of_interest* roi, const float* sin_phi, const float* cos_phi, float delta_s, float delta_t,
+                      const void* const* ptrs)
 {
     const size_t px = f16 ? sizeof(uint16_t) : sizeof(float);
-    if(ctx == nullptr || sin_phi == nullptr || cos_phi == nullptr || p_stride_bytes % px != 0)
+    if(ctx == nullptr || sin_phi == nullptr || cos_phi == nullptr || (ptrs == nullptr && p_stride_bytes % px != 0))
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(n_proj == 0)
         return paris_hip_finish(ctx);
-    // projection p of the batch lives at base + p * stride: consecutive projections must not overlap, and the kernel keeps
-    // the stride as a 32-bit pixel count
-    if(n_proj > 1 && (p_stride_bytes < p_pitch * static_cast<size_t>(p_dim_y) || p_stride_bytes / px > 0xffffffffull))
+    // projection i of the batch lives at base + i * stride (consecutive projections must not overlap), or -- the deferral's
+    // references and snapshots -- wherever ptrs[i] says
+    if(ptrs == nullptr && n_proj > 1 && p_stride_bytes < p_pitch * static_cast<size_t>(p_dim_y))
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    const auto where = [&](uint32_t i) { return ptrs != nullptr ? static_cast<const char*>(ptrs[i]) : static_cast<const char*>(d_p) + static_cast<size_t>(i) * p_stride_bytes; };
 
     // The cross-check variants take the sequence of single-projection launches that the fused kernel is defined to
     // equal, and so does a single projection: that is the tile kernel's case (memory bound, nothing to fuse).
@@ -1264,7 +1402,7 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         int rc = PARIS_HIP_SUCCESS;
         for(uint32_t i = 0; i < n_proj && rc == PARIS_HIP_SUCCESS; ++i)
         {
-            const char* p = static_cast<const char*>(d_p) + i * p_stride_bytes;
+            const char* p = where(i);
             rc = backproject_impl(ctx, p, f16, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo, vol_geo,
                                   enable_roi, roi, sin_phi[i], cos_phi[i], delta_s, delta_t);
         }
@@ -1278,9 +1416,9 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
     for(uint32_t first = 0; first < n_proj; first += FUSED_MAX)
     {
         const uint32_t n = std::min<uint32_t>(FUSED_MAX, n_proj - first);
-        FusedParams fp;
+        FusedParams fp{};
         bool fd = false, skip = false;
-        const char* p0 = reinterpret_cast<const char*>(d_p) + static_cast<size_t>(first) * p_stride_bytes;
+        const char* p0 = where(first);
         if(int rc = fill_params(ctx, p0, f16, p_pitch, p_dim_x, p_dim_y, d_v, v_dim_x, v_dim_y, v_dim_z, v_offset, det_geo,
                                 vol_geo, enable_roi, roi, sin_phi[first], cos_phi[first], delta_s, delta_t, fp.g, fd, skip))
             return rc;
@@ -1305,15 +1443,17 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         fp.g.yfast = x_fast ? 0u : 1u;
         if(ctx->bp_lds_bytes == 0u) // the fused kernel runs 4 workgroups per CU: a 32 KiB box budget (tools/tune_bp.py --fused: +1.7 %)
             fp.g.lds_floats = 32u * 1024u / sizeof(float);
-        fp.proj_stride = static_cast<uint32_t>(p_stride_bytes / px);
-        // fill_params decided the 4-pixel staging from the first projection's address: every later base must be as aligned
-        if(n > 1 && p_stride_bytes % (4u * px) != 0)
-            fp.g.stage_vec4 = 0u;
         for(uint32_t i = 0; i < n; ++i)
         {
             fp.sin_phi[i] = sin_phi[first + i];
             fp.cos_phi[i] = cos_phi[first + i];
+            fp.proj_tab[i] = where(first + i);
+            // fill_params decided the 4-pixel staging from the first projection's address: every later base must be as aligned
+            if(reinterpret_cast<uintptr_t>(fp.proj_tab[i]) % (4u * px) != 0)
+                fp.g.stage_vec4 = 0u;
         }
+        for(uint32_t i = n; i < FUSED_MAX; ++i)
+            fp.proj_tab[i] = fp.proj_tab[0];
         const bool timed = !ctx->bp_start.empty();
         const size_t ev = timed ? static_cast<size_t>(ctx->bp_launches % ctx->bp_start.size()) : 0u;
         if(timed)
@@ -1323,7 +1463,7 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
             PARIS_HIP_TRY(hipEventRecord(ctx->bp_stop[ev], ctx->stream));
         ++ctx->bp_launches;
         for(uint32_t i = 0; i < n && !ctx->upload_targets.empty(); ++i)
-            if(int rc = paris_hip_note_projection_use(ctx, p0 + static_cast<size_t>(i) * p_stride_bytes, p_pitch * p_dim_y))
+            if(int rc = paris_hip_note_projection_use(ctx, where(first + i), p_pitch * p_dim_y))
                 return rc;
     }
     return paris_hip_finish(ctx);
@@ -1371,7 +1511,11 @@ extern "C" int paris_hip_fast_division_is_exact(paris_hip_ctx* ctx, float diviso
     if(exact == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     bool ok = false;
-    if(int rc = fastdiv_is_exact(ctx, divisor, &ok))
+    const int saved = ctx->async_validate;
+    ctx->async_validate = 0; // the question is what the device says: wait for it
+    const int rc = fastdiv_is_exact(ctx, divisor, &ok);
+    ctx->async_validate = saved;
+    if(rc != PARIS_HIP_SUCCESS)
         return rc;
     *exact = ok ? 1 : 0;
     return PARIS_HIP_SUCCESS;

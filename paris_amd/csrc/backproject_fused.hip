@@ -68,8 +68,6 @@ namespace
         const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
         // (Keeping the loop constants of the per-voxel chain in VGPRs -- a plain fp32 multiply / add issues 1.6x faster in
         // isolation when no source is a scalar register, tools/pkbench.hip -- was measured: no gain in this instruction mix.)
-        const char* base = static_cast<const char*>(fp.g.proj);
-        const size_t px = g.proj_f16 ? 2u : 4u;
         // the detector boxes of all projections of this tile, 16 per wave at once (four waves: FUSED_MAX = 64)
         __shared__ int box_tab[FUSED_MAX * BOX_WORDS];
         if(wave * 16u < fp.n_proj)
@@ -78,7 +76,7 @@ namespace
         {
             g.sin_phi = fp.sin_phi[p];
             g.cos_phi = fp.cos_phi[p];
-            g.proj = base + static_cast<size_t>(p) * fp.proj_stride * px;
+            g.proj = fp.proj_tab[p];
 #ifdef PARIS_TIMING_ONLY_NO_BARRIERS // wrong results: prices the two barriers per projection
             if(p == 0u)
 #endif

@@ -970,9 +970,11 @@ namespace
     {
         BpParams g;           // proj = first projection; sin/cos overwritten per projection
         uint32_t n_proj;
-        uint32_t proj_stride; // pixels between consecutive projections
         float sin_phi[FUSED_MAX];
         float cos_phi[FUSED_MAX];
+        // where each projection of the launch lives: a stack one stride apart (paris_hip_backproject_batch, the deferral ring's
+        // snapshots) or the callers' own buffers (deferral by reference: no snapshot was taken)
+        const void* proj_tab[FUSED_MAX];
     };
 }
 

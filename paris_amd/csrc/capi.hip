@@ -135,16 +135,84 @@ extern "C" int paris_hip_ctx_create(int device, void* stream, unsigned flags, pa
 
 int paris_hip_ensure_aux(paris_hip_ctx* ctx)
 {
-    // the validators borrow the upload stream (library-owned, never captured by the caller; a check waits for the uploads queued
-    // before it, milliseconds at most, once per detector): creating a stream costs 2-40 ms, one fewer per ctx
+    // a stream of the validators' own (library-owned, never captured by the caller, nothing else ever queued on it): one stream
+    // create per ctx, absorbed by PARIS_HIP_CTX_WARM
     if(ctx->aux_stream == nullptr)
-    {
-        if(int rc = paris_hip_ensure_upload_stream(ctx))
-            return rc;
-        ctx->aux_stream = ctx->upload_stream;
-    }
+        PARIS_HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     if(ctx->aux_counter == nullptr)
-        PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->aux_counter), sizeof(unsigned long long)));
+        PARIS_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->aux_counter), paris_hip_ctx::AUX_SLOTS * sizeof(unsigned long long)));
+    if(ctx->aux_result == nullptr)
+        PARIS_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->aux_result), paris_hip_ctx::AUX_SLOTS * sizeof(unsigned long long), hipHostMallocDefault));
+    return PARIS_HIP_SUCCESS;
+}
+
+int paris_hip_run_check(paris_hip_ctx* ctx, const std::array<uint32_t, 4>& key, void (*enqueue)(hipStream_t, unsigned long long*, const void*),
+                        const void* arg, bool* ok, bool* known)
+{
+    *ok = false;
+    *known = false;
+    if(int rc = paris_hip_ensure_aux(ctx))
+        return rc;
+    hipStream_t s = ctx->aux_stream;
+    // is this very check running already (asynchronous validation)?
+    for(auto it = ctx->pending_checks.begin(); it != ctx->pending_checks.end(); ++it)
+    {
+        if(it->key != key)
+            continue;
+        const hipError_t state = ctx->async_validate != 0 ? hipEventQuery(it->done) : hipEventSynchronize(it->done);
+        if(state == hipErrorNotReady)
+        {
+            (void)hipGetLastError();
+            return PARIS_HIP_SUCCESS; // still running: not known yet
+        }
+        PARIS_HIP_TRY(state);
+        *ok = ctx->aux_result[it->slot] == 0ull;
+        *known = true;
+        paris_hip_give_event(ctx, it->done);
+        ctx->pending_checks.erase(it);
+        return PARIS_HIP_SUCCESS;
+    }
+    int slot = 0;
+    if(ctx->async_validate != 0)
+    {
+        bool used[paris_hip_ctx::AUX_SLOTS] = {true}; // (slot 0 serves the blocking checks)
+        for(const auto& p : ctx->pending_checks)
+            used[p.slot] = true;
+        for(int i = 1; i < paris_hip_ctx::AUX_SLOTS && slot == 0; ++i)
+            if(!used[i])
+                slot = i;
+    }
+    ctx->aux_result[slot] = ~0ull;
+    PARIS_HIP_TRY(hipMemsetAsync(ctx->aux_counter + slot, 0, sizeof(unsigned long long), s));
+    enqueue(s, ctx->aux_counter + slot, arg);
+    PARIS_HIP_TRY(hipGetLastError());
+    PARIS_HIP_TRY(hipMemcpyAsync(ctx->aux_result + slot, ctx->aux_counter + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if(slot == 0) // blocking (the default), or every asynchronous slot taken
+    {
+        PARIS_HIP_TRY(hipStreamSynchronize(s));
+        *ok = ctx->aux_result[0] == 0ull;
+        *known = true;
+        return PARIS_HIP_SUCCESS;
+    }
+    paris_hip_ctx::pending_check p{key, slot, nullptr};
+    if(int rc = paris_hip_take_event(ctx, &p.done))
+        return rc;
+    const hipError_t err = hipEventRecord(p.done, s);
+    if(err != hipSuccess)
+    {
+        paris_hip_give_event(ctx, p.done);
+        (void)hipStreamSynchronize(s);
+        return static_cast<int>(err);
+    }
+    ctx->pending_checks.push_back(p);
+    return PARIS_HIP_SUCCESS;
+}
+
+extern "C" int paris_hip_set_async_validation(paris_hip_ctx* ctx, int enable)
+{
+    if(ctx == nullptr)
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    ctx->async_validate = enable ? 1 : 0;
     return PARIS_HIP_SUCCESS;
 }
 
@@ -285,9 +353,18 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
         (void)hipStreamDestroy(ctx->bp_stream);
         ctx->bp_stream = nullptr;
     }
-    ctx->aux_stream = nullptr; // (the upload stream under another name: destroyed below)
+    if(ctx->aux_stream != nullptr)
+    {
+        (void)hipStreamSynchronize(ctx->aux_stream); // a validator still running (asynchronous validation) writes the counters below
+        (void)hipStreamDestroy(ctx->aux_stream);
+        ctx->aux_stream = nullptr;
+    }
+    for(auto& p : ctx->pending_checks)
+        (void)hipEventDestroy(p.done);
     if(ctx->aux_counter != nullptr)
         (void)hipFree(ctx->aux_counter);
+    if(ctx->aux_result != nullptr)
+        (void)hipHostFree(ctx->aux_result);
     for(auto& kv : ctx->plans)
     {
         (void)hipFree(kv.second.d_twiddle);
@@ -310,6 +387,11 @@ extern "C" int paris_hip_ctx_destroy(paris_hip_ctx* ctx)
             (void)hipEventDestroy(kv.second.released);
         (void)hipFree(kv.second.ptr);
     }
+    for(auto& z : ctx->defer_zombies) // freed by the caller while a group that was never run referred to them
+        (void)hipFree(z.first);
+    for(hipEvent_t e : ctx->group_events)
+        if(e != nullptr)
+            (void)hipEventDestroy(e);
     for(auto& kv : ctx->host_pool)
     {
         if(kv.second.released != nullptr)
@@ -464,14 +546,35 @@ namespace
         auto it = pool.lower_bound(bytes);
         if(it == pool.end() || it->first != bytes)
             return PARIS_HIP_SUCCESS;
+        // let the caller allocate another one while the rotation is below its capacity. Buffers the caller has freed but the pending
+        // deferred group still refers to (deferral by reference) are part of the rotation: with them counted, a host that runs ahead
+        // of the device waits HERE for the oldest launch's buffers -- two groups in flight behind the one being filled
+        size_t in_rotation = pool.count(bytes);
+        if(&pool == &ctx->proj_pool)
+            for(const auto& z : ctx->defer_zombies)
+                in_rotation += z.second == bytes ? 1u : 0u;
+        const bool may_grow = in_rotation < capacity;
+        if(it->second.group != 0u)
+        {
+            bool done = false;
+            if(int rc = paris_hip_group_done(ctx, it->second.group, false, &done))
+                return rc;
+            if(!done)
+            {
+                if(may_grow)
+                    return PARIS_HIP_SUCCESS;
+                if(int rc = paris_hip_group_done(ctx, it->second.group, true, &done))
+                    return rc;
+            }
+        }
         if(it->second.released != nullptr)
         {
             const hipError_t state = hipEventQuery(it->second.released);
             if(state == hipErrorNotReady)
             {
                 (void)hipGetLastError();
-                if(pool.count(bytes) < capacity)
-                    return PARIS_HIP_SUCCESS; // let the caller allocate another one; the rotation grows up to the capacity
+                if(may_grow)
+                    return PARIS_HIP_SUCCESS;
                 PARIS_HIP_TRY(hipEventSynchronize(it->second.released));
             }
             else
@@ -479,13 +582,54 @@ namespace
             paris_hip_give_event(ctx, it->second.released);
         }
         *out = it->second.ptr;
+        if(&pool == &ctx->proj_pool)
+            ctx->parked_device_bytes -= std::min(ctx->parked_device_bytes, bytes);
         pool.erase(it);
         return PARIS_HIP_SUCCESS;
     }
 
-    // parks a buffer behind its last user: an event recorded on `last` now (everything enqueued there so far), or none at all
-    // when nothing used the buffer (last == nullptr and !used); false when that size's share of the pool is full
-    int pool_park(paris_hip_ctx* ctx, pool_t& pool, size_t bytes, size_t capacity, void* ptr, bool used, hipStream_t last, bool* parked)
+    // is this parked buffer's last user done? (never blocks; an error counts as busy)
+    bool pool_entry_idle(paris_hip_ctx* ctx, const paris_hip_ctx::pooled_buffer& b)
+    {
+        if(b.group != 0u)
+        {
+            bool done = false;
+            if(paris_hip_group_done(ctx, b.group, false, &done) != PARIS_HIP_SUCCESS || !done)
+                return false;
+        }
+        if(b.released != nullptr && hipEventQuery(b.released) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return false;
+        }
+        return true;
+    }
+
+    // the device pool's parked bytes are bounded over ALL sizes. Idle buffers go back to the runtime until the pool is
+    // under the limit again -- sizes other than `keep` first (a driver that moved on to another frame or band size never asks for
+    // the old one again), oldest first inside a size.
+    void pool_trim(paris_hip_ctx* ctx, size_t keep)
+    {
+        for(int pass = 0; pass < 2 && ctx->parked_device_bytes > paris_hip_ctx::PARKED_DEVICE_LIMIT; ++pass)
+            for(auto it = ctx->proj_pool.begin(); it != ctx->proj_pool.end() && ctx->parked_device_bytes > paris_hip_ctx::PARKED_DEVICE_LIMIT;)
+            {
+                if((pass == 0 && it->first == keep) || !pool_entry_idle(ctx, it->second))
+                {
+                    ++it;
+                    continue;
+                }
+                paris_hip_give_event(ctx, it->second.released);
+                (void)hipFree(it->second.ptr);
+                ctx->parked_device_bytes -= std::min(ctx->parked_device_bytes, it->first);
+                it = ctx->proj_pool.erase(it);
+            }
+    }
+
+    // parks a buffer behind its last user: an event recorded on `last` now (everything enqueued there so far), a fused launch that
+    // reads it by reference (group != 0), or nothing at all when nothing used the buffer (last == nullptr and !used); *parked = false
+    // when that size's share of the pool is full
+    int pool_park(paris_hip_ctx* ctx, pool_t& pool, size_t bytes, size_t capacity, void* ptr, bool used, hipStream_t last, bool* parked,
+                  uint64_t group = 0u)
     {
         *parked = false;
         if(pool.count(bytes) >= capacity)
@@ -503,13 +647,98 @@ namespace
             }
         }
         // free-at-once buffers go to the front of their size class (taken first), busy ones behind the older busy ones
-        if(e == nullptr)
-            pool.emplace_hint(pool.lower_bound(bytes), bytes, paris_hip_ctx::pooled_buffer{ptr, e});
+        if(e == nullptr && group == 0u)
+            pool.emplace_hint(pool.lower_bound(bytes), bytes, paris_hip_ctx::pooled_buffer{ptr, e, 0u});
         else
-            pool.emplace(bytes, paris_hip_ctx::pooled_buffer{ptr, e});
+            pool.emplace(bytes, paris_hip_ctx::pooled_buffer{ptr, e, group});
         *parked = true;
+        if(&pool == &ctx->proj_pool)
+        {
+            ctx->parked_device_bytes += bytes;
+            if(ctx->parked_device_bytes > paris_hip_ctx::PARKED_DEVICE_LIMIT)
+                pool_trim(ctx, bytes);
+        }
         return PARIS_HIP_SUCCESS;
     }
+}
+
+int paris_hip_group_done(paris_hip_ctx* ctx, uint64_t group, bool wait, bool* done)
+{
+    *done = false;
+    while(ctx->group_done_seq < group)
+    {
+        const uint64_t next = ctx->group_done_seq + 1u;
+        hipEvent_t e = ctx->group_events[next % paris_hip_ctx::GROUP_EVENTS];
+        if(e == nullptr) // (cannot happen: a group number is handed out with its event recorded)
+            return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+        const hipError_t state = wait ? hipEventSynchronize(e) : hipEventQuery(e);
+        if(state == hipErrorNotReady)
+        {
+            (void)hipGetLastError();
+            return PARIS_HIP_SUCCESS;
+        }
+        PARIS_HIP_TRY(state);
+        ctx->group_done_seq = next;
+    }
+    *done = true;
+    return PARIS_HIP_SUCCESS;
+}
+
+int paris_hip_drain_device_pool(paris_hip_ctx* ctx)
+{
+    if(ctx->proj_pool.empty())
+        return PARIS_HIP_SUCCESS;
+    // every user of a parked buffer was enqueued on one of the ctx's streams
+    PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if(ctx->bp_stream != nullptr)
+        PARIS_HIP_TRY(hipStreamSynchronize(ctx->bp_stream));
+    if(ctx->upload_stream != nullptr)
+        PARIS_HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+    for(auto& kv : ctx->proj_pool)
+    {
+        paris_hip_give_event(ctx, kv.second.released);
+        (void)hipFree(kv.second.ptr);
+    }
+    ctx->proj_pool.clear();
+    ctx->parked_device_bytes = 0;
+    return PARIS_HIP_SUCCESS;
+}
+
+int paris_hip_release_group_references(paris_hip_ctx* ctx, uint64_t group)
+{
+    int rc = PARIS_HIP_SUCCESS;
+    for(auto& z : ctx->defer_zombies)
+    {
+        bool parked = false;
+        int prc = PARIS_HIP_SUCCESS;
+        if(group != 0u) // (always room: what the rotation may hold was settled when the buffers were handed out, pool_take)
+            prc = pool_park(ctx, ctx->proj_pool, z.second, ~size_t{0}, z.first, false, nullptr, &parked, group);
+        if(!parked)
+        {
+            // no room in the pool (or the group was dropped): wait for whatever may still read the buffer, then give it back
+            if(group != 0u)
+            {
+                bool done = false;
+                (void)paris_hip_group_done(ctx, group, true, &done);
+            }
+            else
+                (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(z.first);
+        }
+        if(prc != PARIS_HIP_SUCCESS && rc == PARIS_HIP_SUCCESS)
+            rc = prc;
+    }
+    ctx->defer_zombies.clear();
+    if(ctx->held_count != 0u)
+        for(auto& kv : ctx->proj_allocs)
+            if(kv.second.held != 0u)
+            {
+                kv.second.held = 0u;
+                if(group != 0u)
+                    kv.second.group = group;
+            }
+    ctx->held_count = 0u;
+    return rc;
 }
 
 extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, uint32_t dim_y, float** d_ptr,
@@ -523,11 +752,22 @@ extern "C" int paris_hip_malloc_projection(paris_hip_ctx* ctx, uint32_t dim_x, u
     const size_t row = (static_cast<size_t>(dim_x) * sizeof(float) + 255u) & ~static_cast<size_t>(255u);
     const size_t bytes = row * dim_y;
     void* p = nullptr;
-    if(int rc = pool_take(ctx, ctx->proj_pool, bytes, paris_hip_ctx::device_pool_capacity(bytes), &p))
+    if(int rc = pool_take(ctx, ctx->proj_pool, bytes, ctx->device_pool_capacity(bytes), &p))
         return rc;
     if(p == nullptr)
-        PARIS_HIP_TRY(hipMalloc(&p, bytes));
-    ctx->proj_allocs[p] = paris_hip_ctx::proj_alloc{bytes, false};
+    {
+        hipError_t err = hipMalloc(&p, bytes);
+        if(err == hipErrorOutOfMemory)
+        {
+            // buffers parked in the pools (other sizes, a finished job's rotation) are memory too
+            (void)hipGetLastError();
+            if(int rc = paris_hip_drain_device_pool(ctx))
+                return rc;
+            err = hipMalloc(&p, bytes);
+        }
+        PARIS_HIP_TRY(err);
+    }
+    ctx->proj_allocs[p] = paris_hip_ctx::proj_alloc{bytes, false, 0u, 0u};
     *d_ptr = static_cast<float*>(p);
     *pitch = row;
     return PARIS_HIP_SUCCESS;
@@ -681,7 +921,17 @@ extern "C" int paris_hip_malloc_volume(paris_hip_ctx* ctx, uint32_t dim_x, uint3
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     const size_t bytes = static_cast<size_t>(dim_x) * dim_y * dim_z * sizeof(float);
     void* p = nullptr;
-    PARIS_HIP_TRY(hipMalloc(&p, bytes));
+    {
+        hipError_t err = hipMalloc(&p, bytes);
+        if(err == hipErrorOutOfMemory) // projection buffers parked in the pool are memory too
+        {
+            (void)hipGetLastError();
+            if(int rc = paris_hip_drain_device_pool(ctx))
+                return rc;
+            err = hipMalloc(&p, bytes);
+        }
+        PARIS_HIP_TRY(err);
+    }
     // make_volume_* zero-fills: src/openmp/memory.cpp:46-47, src/cuda/memory.cpp:55-56
     const hipError_t err = hipMemsetAsync(p, 0, bytes, ctx->stream);
     if(err != hipSuccess)
@@ -749,15 +999,37 @@ extern "C" int paris_hip_free(paris_hip_ctx* ctx, void* d_ptr)
         // a projection buffer: deferred backprojections hold their own snapshots, nothing pending refers to it. Its last user
         // was enqueued on the compute stream (every upload into it has been followed by a wait of the compute stream for it)
         const size_t bytes = proj->second.bytes;
-        const bool touched = proj->second.touched;
+        const uint32_t held = proj->second.held;
+        uint64_t group = proj->second.group;
         ctx->proj_allocs.erase(proj);
         paris_hip_forget_upload_target(ctx, d_ptr);
+        if(held != 0u)
+        {
+            // the pending deferred group refers to this very buffer (deferral by reference): it is parked when that group has been
+            // launched, behind the launch (paris_hip_release_group_references) -- no event, no copy, nothing enqueued now
+            ctx->defer_zombies.emplace_back(d_ptr, bytes);
+            return PARIS_HIP_SUCCESS;
+        }
+        if(group != 0u)
+        {
+            bool done = false;
+            if(int rc = paris_hip_group_done(ctx, group, false, &done))
+                return rc;
+            if(done)
+                group = 0u;
+        }
         bool parked = false;
-        (void)touched; // (an event always: work the caller enqueued on the ctx stream itself may use the buffer too)
-        if(int rc = pool_park(ctx, ctx->proj_pool, bytes, paris_hip_ctx::device_pool_capacity(bytes), d_ptr, true, ctx->stream, &parked))
+        // (an event always: work the caller enqueued on the ctx stream itself may use the buffer too)
+        if(int rc = pool_park(ctx, ctx->proj_pool, bytes, ctx->device_pool_capacity(bytes), d_ptr, true, ctx->stream, &parked, group))
             return rc;
         if(parked)
             return PARIS_HIP_SUCCESS;
+        if(group != 0u)
+        {
+            bool done = false;
+            if(int rc = paris_hip_group_done(ctx, group, true, &done))
+                return rc;
+        }
         PARIS_HIP_TRY(hipStreamSynchronize(ctx->stream));
         if(ctx->upload_stream != nullptr)
             PARIS_HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
@@ -862,6 +1134,8 @@ extern "C" int paris_hip_memcpy_projection_h2d(paris_hip_ctx* ctx, float* d_dst,
         return rc;
     if(d_dst == nullptr || h_src == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(int rc = paris_hip_projection_guard(ctx, d_dst, d_pitch * dim_y, ctx->stream, true))
+        return rc;
     PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
                                    hipMemcpyHostToDevice, ctx->stream));
     paris_hip_note_host_use(ctx, h_src, paris_hip_ctx::USED_COMPUTE);
@@ -883,6 +1157,8 @@ extern "C" int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, siz
     if(serial) // diagnostic: PARIS_HIP_UPLOAD_STREAM=0 keeps the copy on the compute stream (A/B of the overlap)
         return paris_hip_memcpy_projection_h2d(ctx, d_dst, d_pitch, h_src, h_pitch, dim_x, dim_y);
     if(int rc = paris_hip_ensure_upload_stream(ctx))
+        return rc;
+    if(int rc = paris_hip_projection_guard(ctx, d_dst, d_pitch * dim_y, ctx->upload_stream, true))
         return rc;
     // Write-after-read on slot reuse: kernels already queued on the compute stream may still read d_dst. The upload waits for
     // the LAST library call that touched this very buffer (paris_hip_note_projection_use records it), not for everything queued:
@@ -939,6 +1215,8 @@ extern "C" int paris_hip_memcpy_projection_d2h(paris_hip_ctx* ctx, float* h_dst,
         return rc;
     if(h_dst == nullptr || d_src == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(int rc = paris_hip_projection_guard(ctx, d_src, d_pitch * dim_y, nullptr, false)) // (a held-back filter of the pending group runs first)
+        return rc;
     PARIS_HIP_TRY(hipMemcpy2DAsync(h_dst, h_pitch, d_src, d_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
                                    hipMemcpyDeviceToHost, ctx->stream));
     paris_hip_note_host_use(ctx, h_dst, paris_hip_ctx::USED_COMPUTE);

@@ -546,6 +546,8 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
     }
     if(int rc = ensure_lds_limit(ctx))
         return rc;
+    if(int rc = paris_hip_projection_guard(ctx, d_p, pitch * dim_y, ctx->stream, true))
+        return rc;
     paris_hip_fft_plan* plan = nullptr;
     if(int rc = paris_hip_get_plan(ctx, filter_size, &plan))
         return rc;
@@ -560,7 +562,18 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
                 return rc;
         const bool fuse = w.active && w.pitch == pitch && w.dim_x == dim_x && w.row_count == dim_y
                           && reinterpret_cast<char*>(w.d_p) + static_cast<size_t>(w.row_first) * w.pitch == reinterpret_cast<char*>(d_p);
-        if(fuse && ctx->filter_deferral != 0 && ctx->defer_depth > 1u && !(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS))
+        bool hold = fuse && ctx->filter_deferral != 0 && ctx->defer_depth > 1u && !(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS);
+        if(hold && ctx->filter_deferral == 2)
+        {
+            // only where nobody can tell: the whole buffer is one of paris_hip_malloc_projection's with the pitch a deferred
+            // backprojection takes BY REFERENCE -- the filter then runs in place, in the group's launch, and every other touch of the
+            // buffer runs it first (paris_hip_projection_guard)
+            auto mine = ctx->proj_allocs.find(d_p);
+            hold = ctx->defer_refs != 0 && w.row_first == 0u && mine != ctx->proj_allocs.end()
+                   && pitch == ((static_cast<size_t>(dim_x) * sizeof(float) + 255u) & ~static_cast<size_t>(255u))
+                   && mine->second.bytes >= pitch * static_cast<size_t>(dim_y);
+        }
+        if(hold)
         {
             // filter deferral: held back with the weighting. A backprojection of this projection takes both along into its ring slot
             // (backproject.hip: defer_backproject); anything else runs them first, in place (paris_hip_flush_pending_weight)
@@ -633,12 +646,20 @@ extern "C" int paris_hip_weight_filter_rows(paris_hip_ctx* ctx, float* d_p, size
         return rc;
     float* rows = reinterpret_cast<float*>(reinterpret_cast<char*>(d_p) + static_cast<size_t>(row_first) * pitch);
     uint16_t* half_rows = d_half ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d_half) + static_cast<size_t>(row_first) * half_pitch) : nullptr;
+    if(int rc = paris_hip_projection_guard(ctx, rows, pitch * row_count, ctx->stream, d_half == nullptr))
+        return rc;
+    if(half_rows != nullptr)
+        if(int rc = paris_hip_projection_guard(ctx, half_rows, half_pitch * row_count, ctx->stream, true))
+            return rc;
     if(int rc = paris_hip_fused_filter_launch(ctx, rows, static_cast<uint32_t>(pitch / sizeof(float)), dim_x, row_count, row_first, true, h_min, v_min,
                                               d_sd, l_px_row, l_px_col, info->d_kp, plan, filter_size, half_rows,
                                               static_cast<uint32_t>(half_pitch / sizeof(uint16_t))))
         return rc;
     if(int rc = paris_hip_note_projection_use(ctx, rows, pitch * row_count))
         return rc;
+    if(half_rows != nullptr) // (the half-precision destination is written by this launch too)
+        if(int rc = paris_hip_note_projection_use(ctx, half_rows, half_pitch * row_count))
+            return rc;
     return paris_hip_finish(ctx);
 }
 
@@ -674,14 +695,24 @@ extern "C" int paris_hip_weight_filter_batch(paris_hip_ctx* ctx, float* d_p, siz
         return rc;
     float* rows = reinterpret_cast<float*>(reinterpret_cast<char*>(d_p) + static_cast<size_t>(row_first) * pitch);
     uint16_t* half_rows = d_half ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d_half) + static_cast<size_t>(row_first) * half_pitch) : nullptr;
+    if(int rc = paris_hip_projection_guard(ctx, rows, pitch * row_count, ctx->stream, d_half == nullptr))
+        return rc;
+    if(half_rows != nullptr)
+        if(int rc = paris_hip_projection_guard(ctx, half_rows, half_pitch * row_count, ctx->stream, true))
+            return rc;
     if(int rc = paris_hip_fused_filter_launch(ctx, rows, static_cast<uint32_t>(pitch / sizeof(float)), dim_x, row_count, row_first, true, h_min, v_min,
                                               d_sd, l_px_row, l_px_col, info->d_kp, plan, filter_size, half_rows,
                                               static_cast<uint32_t>(half_pitch / sizeof(uint16_t)), n_frames, frame_stride / sizeof(float),
                                               half_frame_stride / sizeof(uint16_t)))
         return rc;
-    for(uint32_t f = 0; f < n_frames && !ctx->upload_targets.empty(); ++f)
+    for(uint32_t f = 0; f < n_frames && (!ctx->upload_targets.empty() || !ctx->proj_allocs.empty()); ++f)
+    {
         if(int rc = paris_hip_note_projection_use(ctx, reinterpret_cast<char*>(rows) + f * frame_stride, pitch * row_count))
             return rc;
+        if(half_rows != nullptr)
+            if(int rc = paris_hip_note_projection_use(ctx, reinterpret_cast<char*>(half_rows) + f * half_frame_stride, half_pitch * row_count))
+                return rc;
+    }
     return paris_hip_finish(ctx);
 }
 

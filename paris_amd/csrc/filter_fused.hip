@@ -186,6 +186,8 @@ namespace
 
     __device__ __forceinline__ uint32_t lds_pad(uint32_t i) { return i + (i >> 4); } // one spare slot per 16: conflict-free passes
 
+    constexpr uint32_t FRAME_TAB_MAX = 64u;
+
     struct FusedFilterArgs
     {
         float* p;            // first row of the band
@@ -202,6 +204,10 @@ namespace
         // several frames per launch (grid.y = frame): frame f's band starts frame_stride floats (half_frame_stride halves) behind
         // frame f - 1's; the detector row indices, hence the weights, are the same for every frame
         size_t frame_stride, half_frame_stride;
+        // ... or, frames that do not lie one stride apart (the deferral's projections by reference: the callers' own buffers), the
+        // first band row of each frame (n_tab != 0: at most FRAME_TAB_MAX frames per launch, fp32 in place)
+        uint32_t n_tab;
+        float* frame_tab[FRAME_TAB_MAX];
     };
 
     // HALF: dim_x <= N/2 (always true for the reference's filter length 2 * 2^ceil(log2 n_row)); WEIGHT: apply the cosine
@@ -225,7 +231,7 @@ namespace
         const uint32_t row_a = 2u * blockIdx.x;
         const uint32_t row_b = row_a + 1u;
         const bool has_b = row_b < a.n_rows;
-        float* frame = a.p + static_cast<size_t>(blockIdx.y) * a.frame_stride;
+        float* frame = a.n_tab != 0u ? a.frame_tab[blockIdx.y] : a.p + static_cast<size_t>(blockIdx.y) * a.frame_stride;
         _Float16* half_frame = F16OUT ? a.half_out + static_cast<size_t>(blockIdx.y) * a.half_frame_stride : nullptr;
         float* pa = frame + static_cast<size_t>(row_a) * a.pitch_f;
         float* pb = frame + static_cast<size_t>(row_b) * a.pitch_f;
@@ -590,14 +596,23 @@ int paris_hip_fused_filter_permute_k(paris_hip_ctx* ctx, const float* d_k, uint3
 int paris_hip_fused_filter_launch(paris_hip_ctx* ctx, float* d_rows, uint32_t pitch_f, uint32_t dim_x, uint32_t n_rows, uint32_t row_first,
                                   bool weight, float h_min, float v_min, float d_sd, float l_px_row, float l_px_col, const float* d_kp,
                                   const paris_hip_fft_plan* plan, uint32_t filter_size, uint16_t* d_half, uint32_t half_pitch, uint32_t n_frames,
-                                  size_t frame_stride_f, size_t half_frame_stride)
+                                  size_t frame_stride_f, size_t half_frame_stride, float* const* frame_rows)
 {
     if(n_frames == 0u || n_frames > 65535u)
         return n_frames == 0u ? PARIS_HIP_SUCCESS : PARIS_HIP_ERROR_INVALID_ARGUMENT;
+    if(frame_rows != nullptr && (n_frames > FRAME_TAB_MAX || d_half != nullptr))
+        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     FusedFilterArgs a{};
     a.frame_stride = frame_stride_f;
     a.half_frame_stride = half_frame_stride;
     a.p = d_rows;
+    if(frame_rows != nullptr)
+    {
+        a.n_tab = n_frames;
+        for(uint32_t f = 0; f < FRAME_TAB_MAX; ++f)
+            a.frame_tab[f] = frame_rows[f < n_frames ? f : 0u];
+        a.p = frame_rows[0];
+    }
     a.pitch_f = pitch_f;
     a.dim_x = dim_x;
     a.n_rows = n_rows;

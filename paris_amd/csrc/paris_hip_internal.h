@@ -130,11 +130,14 @@ struct paris_hip_ctx
     {
         void* ptr;
         hipEvent_t released; // nullptr: free at once
+        uint64_t group = 0;  // the fused launch (group_seq) that reads it last, by reference (0: none): free once that group is done
     };
     struct proj_alloc
     {
         size_t bytes = 0;
         bool touched = false; // a library call has read or written it since it was handed out
+        uint32_t held = 0;    // slots of the PENDING deferred group that refer to this buffer itself (no snapshot was taken)
+        uint64_t group = 0;   // the last LAUNCHED group that reads it by reference
     };
     struct host_alloc
     {
@@ -161,20 +164,61 @@ struct paris_hip_ctx
     // a whole group of deferred projections and a few more, as far as 2 GiB go: a host that supplies frames faster than that trickle
     // keeps filling while the launch runs, and the backlog drains in a millisecond once the launch ends (2048^2 frames into a
     // 256-slice slab, filter in place: the loop waited 0.38 ms per frame on its 8 buffers). Device allocations cost ~0.1 ms each.
-    static constexpr size_t device_pool_capacity(size_t bytes)
+    // Deferral by reference (defer_refs): the pending group's buffers are not in the pool at all, the group in flight and the one
+    // queued behind it are parked and busy -- two groups and a few more, as far as 4 GiB go.
+    size_t device_pool_capacity(size_t bytes) const
     {
-        const size_t by_bytes = bytes ? (size_t{2} << 30) / bytes : 56u;
-        return by_bytes < 8u ? 8u : (by_bytes > 56u ? 56u : by_bytes);
+        const size_t want = (defer_refs != 0 && defer_depth > 1u) ? 2u * defer_depth + 8u : 56u;
+        const size_t by_bytes = bytes ? (size_t{defer_refs != 0 ? 4u : 2u} << 30) / bytes : want;
+        return by_bytes < 8u ? 8u : (by_bytes > want ? want : by_bytes);
     }
+    // what the pools of ALL sizes may keep parked per ctx. Beyond it idle buffers (their last user has finished) are
+    // returned to the runtime, other sizes than the one being parked first; on hipErrorOutOfMemory every pool is drained and the
+    // allocation tried once more (paris_hip_drain_device_pool).
+    static constexpr size_t PARKED_DEVICE_LIMIT = size_t{6} << 30;
+    size_t parked_device_bytes = 0;
     // validators (backproject.hip: fast division; validate.hip) never run on the caller's stream -- it may be capturing, or hold
-    // queued work the caller does not want to wait for -- but on the ctx's upload stream (aux_stream is its alias), with an 8-byte
-    // mismatch counter; made on first use (or by PARIS_HIP_CTX_WARM) and kept: creating and destroying a stream per check cost
-    // more than the checks
+    // queued work the caller does not want to wait for -- but on a small stream of the ctx's own (round 4 borrowed the upload
+    // stream: a check could then wait behind uploads that wait for a fused launch), with 8-byte mismatch counters;
+    // made on first use (or by PARIS_HIP_CTX_WARM) and kept: creating and destroying a stream per check cost more than the checks
     hipStream_t aux_stream = nullptr;
-    unsigned long long* aux_counter = nullptr;
+    unsigned long long* aux_counter = nullptr; // AUX_SLOTS mismatch counters on the device (slot 0: the blocking checks)
+    unsigned long long* aux_result = nullptr;  // their values read back, pinned host memory
+    static constexpr int AUX_SLOTS = 8;
+    // Asynchronous validation (paris_hip_set_async_validation; off in the bare library, on in paris::hip): a validator whose answer
+    // is not cached yet is launched and NOT waited for -- the kernels use the compiler's IEEE forms (same bits, a few instructions
+    // more per column) until a later call finds the check finished. The first call of a reconstruction no longer blocks for the
+    // 2.3 ms exhaustive check of the division by the pixel pitch: for 360 small frames that was a tenth of the whole job.
+    int async_validate = 0;
+    struct pending_check
+    {
+        std::array<uint32_t, 4> key;
+        int slot;
+        hipEvent_t done;
+    };
+    std::vector<pending_check> pending_checks;
     std::vector<hipEvent_t> spare_events; // timing-disabled events ready for reuse (pool releases, upload targets)
     // deferred backprojection (paris_hip_set_backproject_deferral): projections copied at call time into a device ring and
     // added by one fused launch per `defer_depth` calls; the key_* fields are the arguments the pending calls share
+    // Deferral BY REFERENCE (paris_hip_set_backproject_references; off in the bare library, on in paris::hip): a call whose projection
+    // is a whole buffer of paris_hip_malloc_projection puts the buffer itself into the group -- no snapshot copy, no ring. The
+    // library then owns what happens to that buffer until the group has run: paris_hip_free() of it only marks it (it is parked
+    // behind the group's launch, ONE event per group), and any other library call that reads or writes it launches the group first
+    // (paris_hip_projection_guard). With filter deferral the held-back weight + filter of such a projection runs IN PLACE, in the
+    // group's one filter launch -- the buffer holds what the caller asked for whenever anything looks at it. Work the caller enqueues
+    // on the ctx stream by itself is invisible to the library: callers that write a projection buffer with kernels of their own
+    // keep the snapshots (the default).
+    int defer_refs = 0;
+    uint32_t held_count = 0;                              // slots of the pending group that are references
+    std::vector<const void*> defer_ptr;                   // per slot of the pending group: where the projection lives
+    std::vector<std::pair<void*, size_t>> defer_zombies;  // buffers the caller freed while the pending group refers to them
+    bool defer_uses_ring = false;                         // the pending group has snapshot slots in ring half defer_half
+    // fused launches in sequence: group g's completion is event group_events[g % GROUP_EVENTS] (recorded behind the launch, on the
+    // stream that ran it; launches complete in sequence order -- every launch is ordered behind the one before it). A slot that
+    // has been recorded again by a later group answers for the earlier one too.
+    static constexpr uint32_t GROUP_EVENTS = 8;
+    hipEvent_t group_events[GROUP_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t group_seq = 0, group_done_seq = 0;
     uint32_t defer_depth = 1; // 1 = immediate
     uint32_t defer_count = 0; // projections pending in the ring
     // The first groups of a reconstruction are launched early -- after 8, 16, 32 ... calls, until the depth is reached -- so that
@@ -266,8 +310,31 @@ inline int paris_hip_note_projection_use(paris_hip_ctx* ctx, const void* d_p, si
 
 void paris_hip_forget_upload_target(paris_hip_ctx* ctx, const void* d_p);
 
+// capi.hip: has fused launch `group` (a paris_hip_ctx::group_seq value) finished? wait = true: blocks until it has
+int paris_hip_group_done(paris_hip_ctx* ctx, uint64_t group, bool wait, bool* done);
+// capi.hip: every parked device buffer goes back to the runtime (after the streams have drained): the answer to hipErrorOutOfMemory
+int paris_hip_drain_device_pool(paris_hip_ctx* ctx);
+// capi.hip: the pending group has been launched as `group` (0: dropped) -- buffers freed meanwhile are parked behind it, the others
+// remember it as their last reader
+int paris_hip_release_group_references(paris_hip_ctx* ctx, uint64_t group);
+// backproject.hip: a library call is about to read (writer == nullptr) or write (on stream `writer`) [d_p, d_p + bytes) of a
+// projection buffer. A buffer the pending deferred group refers to: the group is launched first. A write into a buffer a launched
+// group may still be reading: `writer` is made to wait for that group.
+int paris_hip_projection_guard_slow(paris_hip_ctx* ctx, const void* d_p, size_t bytes, hipStream_t writer, bool writes);
+inline int paris_hip_projection_guard(paris_hip_ctx* ctx, const void* d_p, size_t bytes, hipStream_t writer, bool writes)
+{
+    if(ctx == nullptr || (ctx->held_count == 0u && ctx->group_seq == ctx->group_done_seq))
+        return PARIS_HIP_SUCCESS; // nothing pending by reference, no launch outstanding
+    return paris_hip_projection_guard_slow(ctx, d_p, bytes, writer, writes);
+}
+
 // capi.hip: the ctx's lazily made pieces (PARIS_HIP_CTX_WARM makes them all at once)
 int paris_hip_ensure_aux(paris_hip_ctx* ctx);           // aux_stream + aux_counter
+// capi.hip: runs one validator -- enqueue(stream, counter) launches a kernel that adds its mismatches to *counter -- on the ctx's
+// auxiliary stream. *known = true: *ok is the answer (no mismatch). *known = false (asynchronous validation only): the check is
+// running, ask again later with the same key; the caller uses the unvalidated-safe form meanwhile and caches nothing.
+int paris_hip_run_check(paris_hip_ctx* ctx, const std::array<uint32_t, 4>& key, void (*enqueue)(hipStream_t, unsigned long long*, const void*),
+                        const void* arg, bool* ok, bool* known);
 int paris_hip_ensure_upload_stream(paris_hip_ctx* ctx); // upload_stream + its event ring
 int paris_hip_ensure_bp_stream(paris_hip_ctx* ctx);     // bp_stream + its events
 // backproject.hip / filter.hip / filter_fused.hip / weight.hip / validate.hip: one cheap query per translation unit that makes the
@@ -305,7 +372,8 @@ int paris_hip_fused_filter_permute_k(paris_hip_ctx* ctx, const float* d_k, uint3
 int paris_hip_fused_filter_launch(paris_hip_ctx* ctx, float* d_rows, uint32_t pitch_f, uint32_t dim_x, uint32_t n_rows, uint32_t row_first,
                                   bool weight, float h_min, float v_min, float d_sd, float l_px_row, float l_px_col, const float* d_kp,
                                   const paris_hip_fft_plan* plan, uint32_t filter_size, uint16_t* d_half, uint32_t half_pitch,
-                                  uint32_t n_frames = 1u, size_t frame_stride_f = 0u, size_t half_frame_stride = 0u);
+                                  uint32_t n_frames = 1u, size_t frame_stride_f = 0u, size_t half_frame_stride = 0u,
+                                  float* const* frame_rows = nullptr); // frame_rows: the first band row of each frame instead of d_rows + f * stride
 
 // backproject.hip: runs the projections pending in the deferral ring (no-op when there are none). Called by every entry
 // point that observes or changes a volume, completes work, or changes how backprojection runs.

@@ -56,26 +56,24 @@ namespace
     std::mutex lean_mutex;
     std::map<std::pair<int, std::array<uint32_t, 4>>, bool> lean_cache; // (device, key) -> validation result, process-wide
 
-    // Runs one validator launch on the ctx's auxiliary stream (never the caller's: it may be capturing, or hold queued work the
-    // caller does not want to wait for) and reads the mismatch count back. kind 0: division, 1: weighting.
-    int run_validator(paris_hip_ctx* ctx, int kind, uint32_t first, uint64_t count, float a, float b, bool* ok)
+    // one validator launch (capi.hip: paris_hip_run_check puts it on the ctx's auxiliary stream -- never the caller's, which may be
+    // capturing or hold queued work the caller does not want to wait for -- and reads the mismatch count back)
+    struct lean_launch
     {
-        *ok = false;
-        if(int rc = paris_hip_ensure_aux(ctx))
-            return rc;
-        hipStream_t s = ctx->aux_stream;
-        unsigned long long bad = ~0ull;
-        PARIS_HIP_TRY(hipMemsetAsync(ctx->aux_counter, 0, sizeof(bad), s));
-        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>(4096u, std::max<uint64_t>(1u, (count + 255u) / 256u)));
-        if(kind == 0)
-            hipLaunchKernelGGL(lean_div_validate_kernel, dim3(blocks), dim3(256), 0, s, first, count, a, b, ctx->aux_counter);
+        int kind; // 0: division, 1: weighting
+        uint32_t first;
+        uint64_t count;
+        float a, b;
+    };
+
+    void lean_enqueue(hipStream_t s, unsigned long long* counter, const void* arg)
+    {
+        const lean_launch& l = *static_cast<const lean_launch*>(arg);
+        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>(4096u, std::max<uint64_t>(1u, (l.count + 255u) / 256u)));
+        if(l.kind == 0)
+            hipLaunchKernelGGL(lean_div_validate_kernel, dim3(blocks), dim3(256), 0, s, l.first, l.count, l.a, l.b, counter);
         else
-            hipLaunchKernelGGL(lean_weight_validate_kernel, dim3(blocks), dim3(256), 0, s, first, count, a, ctx->aux_counter);
-        PARIS_HIP_TRY(hipGetLastError());
-        PARIS_HIP_TRY(hipMemcpyAsync(&bad, ctx->aux_counter, sizeof(bad), hipMemcpyDeviceToHost, s)); // pageable destination: staged by the runtime
-        PARIS_HIP_TRY(hipStreamSynchronize(s));
-        *ok = bad == 0ull;
-        return PARIS_HIP_SUCCESS;
+            hipLaunchKernelGGL(lean_weight_validate_kernel, dim3(blocks), dim3(256), 0, s, l.first, l.count, l.a, counter);
     }
 
     uint32_t bits_of(float x)
@@ -96,11 +94,17 @@ namespace
             auto pit = lean_cache.find(pkey);
             if(pit == lean_cache.end())
             {
-                bool exact = false;
+                bool exact = false, known = false;
                 if(int rc = paris_hip_bind(ctx))
                     return rc;
-                if(int rc = run_validator(ctx, kind, first, count, a, b, &exact))
+                const lean_launch l{kind, first, count, a, b};
+                if(int rc = paris_hip_run_check(ctx, key, lean_enqueue, &l, &exact, &known))
                     return rc;
+                if(!known) // asynchronous validation: still running -- the compiler's IEEE forms serve meanwhile (*ok stays false)
+                {
+                    *ok = false;
+                    return PARIS_HIP_SUCCESS;
+                }
                 pit = lean_cache.emplace(pkey, exact).first;
             }
             it = ctx->lean_checks.emplace(key, pit->second).first;
@@ -164,10 +168,12 @@ extern "C" int paris_hip_lean_division_is_exact(paris_hip_ctx* ctx, float d_sd, 
     if(exact == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     bool ok = false;
-    const int saved = ctx->lean_validate;
-    ctx->lean_validate = 1; // the question is what the device says, whatever the tuning switch
+    const int saved = ctx->lean_validate, saved_async = ctx->async_validate;
+    ctx->lean_validate = 1; // the question is what the device says, whatever the tuning switches: wait for it
+    ctx->async_validate = 0;
     const int rc = paris_hip_lean_division_check(ctx, d_sd, d_so, &ok);
     ctx->lean_validate = saved;
+    ctx->async_validate = saved_async;
     *exact = ok ? 1 : 0;
     return rc;
 }
@@ -179,10 +185,12 @@ extern "C" int paris_hip_lean_weighting_is_exact(paris_hip_ctx* ctx, float d_sd,
     if(exact == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     bool ok = false;
-    const int saved = ctx->lean_validate;
+    const int saved = ctx->lean_validate, saved_async = ctx->async_validate;
     ctx->lean_validate = 1;
+    ctx->async_validate = 0;
     const int rc = paris_hip_lean_weighting_check(ctx, d_sd, static_cast<double>(q_lo), static_cast<double>(q_hi), &ok);
     ctx->lean_validate = saved;
+    ctx->async_validate = saved_async;
     *exact = ok ? 1 : 0;
     return rc;
 }

@@ -73,6 +73,9 @@ extern "C" int paris_hip_weight_rows(paris_hip_ctx* ctx, float* d_p, size_t pitc
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(dim_x == 0 || row_count == 0)
         return paris_hip_finish(ctx);
+    // (deferral by reference: a buffer the pending group reads must not be weighted again before that group has run)
+    if(int rc = paris_hip_projection_guard(ctx, d_p, pitch * dim_y, ctx->stream, true))
+        return rc;
     if(ctx->stage_fusion != 0 && !(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS))
     {
         // held back: the filter call that follows weights in its load (one launch, 8 instead of 16 bytes of traffic per pixel)
@@ -109,7 +112,7 @@ extern "C" int paris_hip_set_filter_deferral(paris_hip_ctx* ctx, int enable)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(int rc = paris_hip_flush_deferred(ctx)) // (runs a held-back weighting / filter as well)
         return rc;
-    ctx->filter_deferral = enable ? 1 : 0;
+    ctx->filter_deferral = enable == 2 ? 2 : (enable ? 1 : 0);
     return PARIS_HIP_SUCCESS;
 }
 

@@ -22,18 +22,15 @@
 #ifndef PARIS_HIP_STAGE_FUSION
 #define PARIS_HIP_STAGE_FUSION 1
 #endif
-// 1: the apply_filter() of that pair is held back too when the projection is backprojected next, and weighting + filter run on the
-// library's snapshots, one launch per group of deferred backprojections (paris_hip_set_filter_deferral: what small projections
-// need when the GPU is the limit -- their single launches are mostly latency). The projection's own buffer then keeps its
-// unfiltered pixels; PARIS's loop destroys it right after backproject() (src/main.cpp:98-105). 0 (default): the filter runs when
-// it is called, in place -- the switch would change what the caller's buffer holds behind its back, and it buys PARIS's loop nothing
-// that the buffer rotation does not: a per-projection filter launch cannot share the chip with a running fused launch (its waves do
-// not fit beside four fused waves per SIMD; 3.3-3.8 ms per 2048^2 frame instead of 19 us), and with 8 device buffers in rotation the
-// loop stalled on them where a group's launch is short (2048^2 frames into the 256-slice slab of the 8-GPU configuration: 1138 GVox/s
-// against 1847 with the switch); since the rotation holds a whole group (device_pool_capacity) both ways run at the host's own
-// frame rate there (1790-1850), and everywhere else they measure the same (profiles/r04_ab_filter_deferral_in_the_mirror.txt).
+// 2 (default): the apply_filter() of that pair is held back too when nobody can tell -- the projection is a make_projection_device
+// buffer that a deferred backproject() takes by reference (PARIS_HIP_BACKPROJECT_REFERENCES): weighting + filter then run IN PLACE, one
+// launch for the whole group right before its fused backprojection, and every other call that touches the buffer runs them first
+// (paris_hip_set_filter_deferral(2)). 1: held back whenever a backprojection follows (a snapshotted projection's own buffer then
+// keeps its unfiltered pixels). 0: the filter runs when it is called. Round 4 left this off: the ring's snapshots made it visible
+// in the caller's buffer, and the loop was bound elsewhere; with references it is invisible and removes a launch per projection
+// from the host's path (profiles/r05_demo_paris_hip_mirror.txt).
 #ifndef PARIS_HIP_FILTER_DEFERRAL
-#define PARIS_HIP_FILTER_DEFERRAL 0
+#define PARIS_HIP_FILTER_DEFERRAL 2
 #endif
 // 1: every backend call returns after its work has finished, like the reference's backends (stream sync before return:
 // src/cuda/weighting.cu:72, filtering.cu:260, backprojection.cu:236). 0 (default): calls enqueue and return; only the
@@ -49,6 +46,14 @@
 // observer of the volume behind the launches; results are bit-identical. 0: one stream for everything.
 #ifndef PARIS_HIP_BACKPROJECT_OVERLAP
 #define PARIS_HIP_BACKPROJECT_OVERLAP 1
+#endif
+
+// 1 (default): a deferred backproject() of a make_projection_device buffer takes no snapshot -- the group's fused launch reads the
+// buffer itself, the buffer PARIS's loop frees right after the call (src/main.cpp:98-105, src/loader.cpp:28-33) goes back to the
+// pool behind that launch, and anything else that touches it first launches the group (paris_hip_set_backproject_references). 0:
+// every call snapshots its projection into the library's ring.
+#ifndef PARIS_HIP_BACKPROJECT_REFERENCES
+#define PARIS_HIP_BACKPROJECT_REFERENCES 1
 #endif
 
 #include <cstddef>
@@ -148,6 +153,10 @@ namespace paris
                 detail::construction_check(paris_hip_set_stage_fusion(c, PARIS_HIP_STAGE_FUSION), "set_device()");
                 detail::construction_check(paris_hip_set_filter_deferral(c, PARIS_HIP_FILTER_DEFERRAL), "set_device()");
                 detail::construction_check(paris_hip_set_backproject_overlap(c, PARIS_HIP_BACKPROJECT_OVERLAP), "set_device()");
+                detail::construction_check(paris_hip_set_backproject_references(c, PARIS_HIP_BACKPROJECT_REFERENCES && !PARIS_HIP_SYNCHRONOUS_CALLS),
+                                           "set_device()");
+                // validators of the hand-expanded IEEE sequences run beside the first projections instead of in front of them
+                detail::construction_check(paris_hip_set_async_validation(c, !PARIS_HIP_SYNCHRONOUS_CALLS), "set_device()");
                 it = s.per_device.emplace(d, std::unique_ptr<paris_hip_ctx, detail::ctx_deleter>{c}).first;
             }
             s.current = it->second.get();
@@ -280,8 +289,13 @@ namespace paris
         inline auto make_subvolume_information(const volume_geometry& vol_geo, const detector_geometry& det_geo) -> subvolume_info
         {
             paris_subvolume_info c_info{};
-            detail::construction_check(paris_hip_make_subvolume_information(detail::as_c<paris_volume_geometry>(vol_geo),
-                                                                            detail::as_c<paris_detector_geometry>(det_geo), 0, &c_info),
+            // beside the slab a device also holds this backend's projection buffers: the rotation of make_projection_device buffers
+            // and the pending group (or the snapshot ring) -- they do not shrink when the slab count doubles
+            std::size_t reserve = 0;
+            detail::construction_check(paris_hip_projection_reserve_bytes(current_ctx(), det_geo.n_row, det_geo.n_col, &reserve),
+                                       "make_subvolume_information()");
+            detail::construction_check(paris_hip_make_subvolume_information_reserving(detail::as_c<paris_volume_geometry>(vol_geo),
+                                                                                      detail::as_c<paris_detector_geometry>(det_geo), 0, reserve, &c_info),
                                        "make_subvolume_information()");
             subvolume_info info{};
             info.geo.dim_x = c_info.geo.dim_x;
