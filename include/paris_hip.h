@@ -198,7 +198,8 @@ int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pitch, uint32_
 
 /* Row-filter kernel: 0 = default (filter_size >= 1024 and a K of paris_hip_make_filter*: radix-16 register passes with
  * table twiddles, the kernel that can also weight in its load; radix-2 below 1024), 1 = the radix-2 kernel for every size,
- * 2 = the first radix-16 kernel (twiddles formed per stage). Same transform; results differ by fp32 rounding only. */
+ * 2 = the first radix-16 kernel (twiddles formed per stage; experiments build only: paris_hip_has_experiments, else
+ * PARIS_HIP_ERROR_UNSUPPORTED). A K this ctx did not make runs the radix-2 kernel. Same transform; results differ by fp32 rounding only. */
 int paris_hip_set_filter_variant(paris_hip_ctx* ctx, int variant);
 
 /* Extension: stage fusion. With enable != 0 a paris_hip_weight / paris_hip_weight_rows call is held back, and the
@@ -434,6 +435,11 @@ int paris_hip_stage_backproject(paris_hip_ctx* ctx, const float* d_p, size_t p_p
 const char* paris_hip_strerror(int status);
 /* library version "major.minor.patch" */
 const char* paris_hip_version(void);
+/* 1: this library is the experiments build (make -C paris_amd/csrc EXPERIMENTS=1 -> libparis_hip_experiments.so): the kernels,
+ * tile orders and A/B switches that were measured and lost are compiled in. 0: the product build -- its setters answer
+ * PARIS_HIP_ERROR_UNSUPPORTED for them (backprojection variants 3 and 5, unroll 3 and 4, the slice shapes, tile orders 0 / 1 / 8 /
+ * 9 / 12, filter variant 2). Results never depend on any of them. */
+int paris_hip_has_experiments(void);
 /* Times the most recent backproject launch on this ctx (HIP events recorded on the ctx stream around the
  * kernel); synchronises the stream. Used by bench.py for roofline.achieved. */
 int paris_hip_last_backproject_ms(paris_hip_ctx* ctx, float* ms);
@@ -447,15 +453,17 @@ int paris_hip_backproject_timing_collect(paris_hip_ctx* ctx, float* ms, uint32_t
  * without LDS (slow, for cross-checking), 2 = tile kernel (z-walk per workgroup), 3 = slice kernel (one slice per
  * wave; needs a 16-byte aligned volume with dim_x % 4 == 0, else falls back to 2), 4 = the fused kernel run with one
  * projection (every slice of a tile in flight before the first store; measured 5 % slower than the tile kernel). All give
- * identical bits.
+ * identical bits. 3 and 5 (the two-pass variant: column constants of the whole plane precomputed per projection) were measured
+ * slower and exist in the experiments build only (PARIS_HIP_ERROR_UNSUPPORTED in the product).
  * paris_hip_backproject_batch uses its fused kernel under variant 0 and runs one launch per projection otherwise. */
 int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant);
 /* Tuning knobs of the LDS-staged kernel; 0 keeps the default. vx: voxels per lane along x (1, 2, 4; capped by
  * the volume's alignment), unroll: z slices in flight per lane (1, 2, 4; 3 = one at a time with the next one prefetched), tz: slices per tile, lds_bytes: LDS
- * budget per workgroup for the staged detector box (1024..65536). Results do not depend on any of them. */
+ * budget per workgroup for the staged detector box (1024..65536). Results do not depend on any of them. The launcher picks unroll 1 or 2
+ * by itself; 3 and 4 are compiled into the experiments build only (PARIS_HIP_ERROR_UNSUPPORTED in the product). */
 int paris_hip_set_backproject_tuning(paris_hip_ctx* ctx, int vx, int unroll, int tz, int lds_bytes);
 /* Shape of the slice kernel: waves (= slices per tile) x row groups per lane; (16,4) (16,2) (8,4) (8,2) (8,1),
- * (0,0) = default. */
+ * (0,0) = default. Experiments build only (the product has no slice kernel: PARIS_HIP_ERROR_UNSUPPORTED for anything but (0,0)). */
 int paris_hip_set_backproject_slice_shape(paris_hip_ctx* ctx, int waves, int row_groups);
 /* Workgroup -> tile order (-1 default by volume shape: 15 for planes beyond 1024^2, else 18, or 5 when the z tiles do not divide among the 8 XCDs; 0 x-fastest, 1 z-fastest, 5 one
  * contiguous run of tiles per XCD, 8 one band of y tiles per XCD swept x -> z -> y, 9 the same swept x -> y -> z, 12 order 8 in chunks
@@ -463,7 +471,8 @@ int paris_hip_set_backproject_slice_shape(paris_hip_ctx* ctx, int waves, int row
  * dealt to the XCDs) and the cache
  * policy of the volume stream (2 nontemporal loads with write-through nontemporal stores, 1 nontemporal, 0 plain, -1 library
  * default: plain for slabs that largely stay in the Infinity Cache between launches, up to 384 MiB, 2 for larger ones).
- * Performance only. */
+ * Performance only. The product build has the orders the launcher picks from, 5 and 14 .. 18; 0 / 1 / 8 / 9 / 12 lost and are
+ * compiled into the experiments build only (PARIS_HIP_ERROR_UNSUPPORTED). */
 int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, int nontemporal);
 /* The per-voxel division by the detector pixel pitch may run as multiply + 2 FMA instead of the IEEE sequence,
  * but only for a divisor for which an exhaustive GPU check over all 2^32 fp32 dividends (once per ctx and divisor)

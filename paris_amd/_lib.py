@@ -6,7 +6,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libparis_hip.so")
+# the product library; PARIS_HIP_LIBRARY names another build of the same C ABI -- the experiments build of `make EXPERIMENTS=1`
+# (lib/libparis_hip_experiments.so: the kernels, tile orders and switches that lost their A/B runs) for tools/ and the variant tests
+EXPERIMENTS_LIB_PATH = os.path.join(_HERE, "lib", "libparis_hip_experiments.so")
+LIB_PATH = os.environ.get("PARIS_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libparis_hip.so")
 
 SUCCESS = 0
 ERROR_INVALID_ARGUMENT = 10001
@@ -129,6 +132,7 @@ SIGNATURES = {
     "paris_hip_set_backproject_overlap": (C.c_int, [_vp, C.c_int]),
     "paris_hip_set_backproject_references": (C.c_int, [_vp, C.c_int]),
     "paris_hip_set_async_validation": (C.c_int, [_vp, C.c_int]),
+    "paris_hip_has_experiments": (C.c_int, []),
     "paris_hip_projection_reserve_bytes": (C.c_int, [_vp, _u32, _u32, _P(_sz)]),
     "paris_hip_slab_row_band": (C.c_int, [_P(DetectorGeometry), _P(VolumeGeometry), _u32, _u32, _u32, _u32, C.c_int,
                                           _P(RegionOfInterest), _P(_u32), _P(_u32)]),
@@ -175,6 +179,11 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def has_experiments():
+    """True when the loaded library is the experiments build (make EXPERIMENTS=1)"""
+    return bool(load().paris_hip_has_experiments())
 
 
 class ParisHipError(RuntimeError):

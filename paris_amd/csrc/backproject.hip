@@ -53,6 +53,7 @@ namespace
     // Tile kernel (z-walk in time). 1-D grid over ntx * nty * ntz tiles of 64 x TY x g.tz voxels, TY = 4*VX.
     // Serves every alignment (VX = 1, 2, 4).
     // --------------------------------------------------------------------------------------------
+#ifdef PARIS_HIP_EXPERIMENTS // measured slower: only in the experiments build (make EXPERIMENTS=1)
     // Two-pass variant, pass A: the z-invariant constants of every (x,y) column of the slab's plane for this projection,
     // computed once instead of once per tile (src/openmp/backprojection.cpp:116-129,139): three planes factor / h / u.
     template <bool FD>
@@ -70,6 +71,7 @@ namespace
         st[2u * plane + at] = c.u;
     }
 
+#endif // PARIS_HIP_EXPERIMENTS
 #ifndef PARIS_TILE_MIN_WAVES
 #define PARIS_TILE_MIN_WAVES 1
 #endif
@@ -207,6 +209,7 @@ namespace
             walk(std::false_type{}); // some tap of this lane may leave the staged box: per-voxel check + global path
     }
 
+#ifdef PARIS_HIP_EXPERIMENTS // measured slower than the tile kernel: only in the experiments build
     // --------------------------------------------------------------------------------------------
     // Slice kernel (z across waves). A workgroup of NW waves owns a tile of 64 x (4*RPL) columns x NW slices; wave w
     // updates slice w, so a thread issues its RPL 16-byte loads once, updates 4*RPL voxels and stores: the volume
@@ -320,6 +323,7 @@ namespace
                 store_voxels<4, NT>(vp + r * row4, acc[r]);
     }
 
+#endif // PARIS_HIP_EXPERIMENTS
     // --------------------------------------------------------------------------------------------
     // Cross-check kernel (variant 1): one thread per voxel, taps straight from global memory, the
     // reference's loop body verbatim in structure. Slow; used by tests to validate the tile kernel.
@@ -384,12 +388,14 @@ namespace
     template <int VX, bool NT, bool FD>
     void launch_tile_unroll(BpParams& g, int unroll, hipStream_t stream)
     {
-        switch(unroll)
+        switch(unroll) // the bodies the launcher picks by itself are 1 and 2; 3 and 4 exist in the experiments build (tuning)
         {
             case 1: launch_tile<VX, 1, NT, FD>(g, stream); break;
-            case 2: launch_tile<VX, 2, NT, FD>(g, stream); break;
+#ifdef PARIS_HIP_EXPERIMENTS
             case 3: launch_tile<VX, 3, NT, FD>(g, stream); break; // 1 + prefetch of the next slice
-            default: launch_tile<VX, 4, NT, FD>(g, stream); break;
+            case 4: launch_tile<VX, 4, NT, FD>(g, stream); break;
+#endif
+            default: launch_tile<VX, 2, NT, FD>(g, stream); break;
         }
     }
 
@@ -406,6 +412,7 @@ namespace
             launch_tile_unroll<VX, false, false>(g, unroll, stream);
     }
 
+#ifdef PARIS_HIP_EXPERIMENTS // the two-pass variant and the slice kernel's launchers
     // two-pass variant (variant 5): pass A writes the column constants of the whole plane, pass B is the tile kernel reading them
     template <int UNROLL, bool FD>
     void launch_tile_pre(BpParams& g, hipStream_t stream)
@@ -465,6 +472,7 @@ namespace
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     }
 
+#endif // PARIS_HIP_EXPERIMENTS
     // Is div_by_constant exact for this divisor? Checked once per process, device and divisor on the GPU (about 2 ms): the
     // result is a property of the divisor, so it is cached process-wide (every ctx of every host thread shares it) and the
     // check runs on a private blocking-free stream of its own -- never on the caller's stream, which may be capturing or may
@@ -670,7 +678,11 @@ static int fill_params(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_p
         // nesting inside the dealt orders (BpParams::yfast): deep volumes run a group's y tiles before the next z tile (2048^3: 0.7754 ->
         // 0.7774, 0.7757 -> 0.7784; the 2048^3 ROI of config 5: 0.7387 -> 0.7396, 0.7384 -> 0.7400), a 256-slice slab keeps the z tile
         // first (0.7584 -> 0.7565, 0.7572 -> 0.7540 with the other nesting); same device, interleaved, profiles/r03_ab_tile_order.txt
+#ifdef PARIS_HIP_EXPERIMENTS
         static const int tile_nest = std::getenv("PARIS_TILE_NEST") ? std::atoi(std::getenv("PARIS_TILE_NEST")) : -1; // A/B switch
+#else
+        constexpr int tile_nest = -1;
+#endif
         g.yfast = tile_nest >= 0 ? static_cast<uint32_t>(tile_nest) : (v_dim_z > 256u ? 2u : 0u); // (round 4: with the 16-slice tiles, from 257 slices: +0.15 % at 512, +0.25 % at 1024)
     }
     // (y tiles fastest is for the fused kernel's box sharing; the volume stream of this kernel loses with it: 2048^3 0.772 -> 0.662, 1024^3 0.743 -> 0.567)
@@ -762,6 +774,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
             g.lds_floats = 40u * 1024u / sizeof(float);
         const int unroll = ctx->bp_unroll ? ctx->bp_unroll : ((g.tz == 8u && ctx->bp_tz == 0u) || (deep_big && ctx->bp_lds_bytes == 0u && vx == 4) ? 1 : 2);
         const bool nt = volume_stream_policy(ctx, v_dim_x, v_dim_y, v_dim_z) != 0;
+#ifdef PARIS_HIP_EXPERIMENTS
         const bool want_slice = ctx->bp_variant == 3; // measured slower than the tile kernel so far: opt-in only
         if(want_slice && vx == 4)
         {
@@ -791,7 +804,9 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
             else
                 fd ? launch_tile_pre<2, true>(g, ctx->stream) : launch_tile_pre<2, false>(g, ctx->stream);
         }
-        else if(vx == 4)
+        else
+#endif // PARIS_HIP_EXPERIMENTS
+        if(vx == 4)
             launch_tile_flags<4>(g, unroll, nt, fd, ctx->stream);
         else if(vx == 2)
             launch_tile_flags<2>(g, unroll, nt, fd, ctx->stream);
@@ -1439,7 +1454,11 @@ static int batch_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pi
         // and 180 degrees), the mean over the circle from 319 to 74 GB against 35 GB of compulsory reads, and the launch got 4 % faster
         // (profiles/r03_ab_fused_traffic.txt). Wider groups cut the misses further (64 rows: 57 GB, 128: 48) but unbalance the XCDs'
         // shares of skipped tiles: -1 % and -3 %.
+#ifdef PARIS_HIP_EXPERIMENTS
         static const bool x_fast = std::getenv("PARIS_FUSED_XFAST") != nullptr; // A/B switch: the single-projection kernel's nesting
+#else
+        constexpr bool x_fast = false;
+#endif
         fp.g.yfast = x_fast ? 0u : 1u;
         if(ctx->bp_lds_bytes == 0u) // the fused kernel runs 4 workgroups per CU: a 32 KiB box budget (tools/tune_bp.py --fused: +1.7 %)
             fp.g.lds_floats = 32u * 1024u / sizeof(float);
@@ -1489,6 +1508,10 @@ extern "C" int paris_hip_set_backproject_variant(paris_hip_ctx* ctx, int variant
         return rc;
     if(ctx == nullptr || variant < 0 || variant > 5)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+#ifndef PARIS_HIP_EXPERIMENTS
+    if(variant == 3 || variant == 5) // the slice kernel and the two-pass variant lost and live in the experiments build only
+        return PARIS_HIP_ERROR_UNSUPPORTED;
+#endif
     ctx->bp_variant = variant;
     return PARIS_HIP_SUCCESS;
 }
@@ -1499,6 +1522,10 @@ extern "C" int paris_hip_set_backproject_order(paris_hip_ctx* ctx, int order, in
         return rc;
     if(ctx == nullptr || !(order == -1 || order == 0 || order == 1 || order == 5 || order == 8 || order == 9 || order == 12 || (order >= 14 && order <= 18)) || nontemporal < -1 || nontemporal > 2)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+#ifndef PARIS_HIP_EXPERIMENTS
+    if(order == 0 || order == 1 || order == 8 || order == 9 || order == 12) // the orders that lost: experiments build only
+        return PARIS_HIP_ERROR_UNSUPPORTED;
+#endif
     ctx->bp_order = order;
     ctx->bp_nt = nontemporal; // < 0: automatic (by slab size)
     return PARIS_HIP_SUCCESS;
@@ -1562,6 +1589,10 @@ extern "C" int paris_hip_set_backproject_slice_shape(paris_hip_ctx* ctx, int wav
                     || (waves == 8 && (row_groups == 4 || row_groups == 2 || row_groups == 1));
     if(!ok)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+#ifndef PARIS_HIP_EXPERIMENTS
+    if(waves != 0) // there is no slice kernel in this build
+        return PARIS_HIP_ERROR_UNSUPPORTED;
+#endif
     ctx->bp_slice_nw = waves;
     ctx->bp_slice_rpl = row_groups;
     return PARIS_HIP_SUCCESS;
@@ -1578,9 +1609,24 @@ extern "C" int paris_hip_set_backproject_tuning(paris_hip_ctx* ctx, int vx, int 
     if(tz < 0 || tz > 4096 || lds_bytes < 0 || lds_bytes > static_cast<int>(LDS_BYTES_MAX)
        || (lds_bytes != 0 && lds_bytes < 1024))
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+#ifndef PARIS_HIP_EXPERIMENTS
+    if(unroll > 2) // the launcher picks 1 or 2 by itself; the other bodies are compiled into the experiments build only
+        return PARIS_HIP_ERROR_UNSUPPORTED;
+#endif
     ctx->bp_vx = vx;
     ctx->bp_unroll = unroll;
     ctx->bp_tz = static_cast<uint32_t>(tz);
     ctx->bp_lds_bytes = static_cast<uint32_t>(lds_bytes);
     return PARIS_HIP_SUCCESS;
+}
+
+// 1: this library was built with make EXPERIMENTS=1 -- the kernels, tile orders and switches that lost their A/B runs are compiled in
+// (tools/, the variant tests); 0: the product build
+extern "C" int paris_hip_has_experiments(void)
+{
+#ifdef PARIS_HIP_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }

@@ -5,6 +5,9 @@
 // rate of the plain instructions (tools/pkbench.hip) and need v_mov packing on top: -fno-slp-vectorize (Makefile) is
 // worth +12 % here, while the memory-bound tile kernel in backproject.hip is indifferent to it.
 #define PARIS_BP_SINGLE_INSTRUCTION_FLOOR 1
+#if (defined(PARIS_TIMING_ONLY_NO_BARRIERS) || defined(PARIS_TIMING_ONLY_STAGE_ONCE)) && !defined(PARIS_HIP_EXPERIMENTS)
+#error "the timing-only switches compute WRONG results: they exist in the experiments build only (make EXPERIMENTS=1)"
+#endif
 #include "bp_device.h"
 
 namespace

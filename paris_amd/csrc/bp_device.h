@@ -160,10 +160,12 @@ namespace
         const uint64_t total = static_cast<uint64_t>(g.ntx) * g.nty * g.ntz;
         if(g.order == 5u)
             return ((total + 7u) / 8u) * 8u;
+#ifdef PARIS_HIP_EXPERIMENTS
         if(g.order == 8u || g.order == 9u)
             return 8ull * ((g.nty + 7u) / 8u) * g.ntx * g.ntz;
         if(g.order == 12u)
             return 8ull * ((g.nty + 7u) / 8u) * g.ntx * g.zchunk * ((g.ntz + g.zchunk - 1u) / g.zchunk);
+#endif
         if(g.order == 18u) // z tiles dealt: 8 XCDs x whole planes x whole rounds, then the planes left over with their y tiles dealt
             return 8ull * (static_cast<uint64_t>(g.ntx) * g.nty * (g.ntz / 8u)
                            + static_cast<uint64_t>(g.ntz % 8u) * dealt_band(g.nty, 14u + order18_tail_group_log2(g)) * g.ntx);
@@ -238,6 +240,7 @@ namespace
     __device__ __forceinline__ bool tile_of_block(const BpParams& g, uint32_t b, uint32_t& bx, uint32_t& by, uint32_t& bz)
     {
         const uint32_t total = g.ntx * g.nty * g.ntz;
+#ifdef PARIS_HIP_EXPERIMENTS // orders 1, 8 (and 9, 12 below): the mappings that lost; the product build has 5 and 14 .. 18
         if(g.order == 1u)
         {
             if(b >= total)
@@ -262,6 +265,7 @@ namespace
             by = xcd * band + yb;
             return yb < band && by < g.nty;
         }
+#endif
         if(g.order == 18u)
         {
             // z tiles dealt to the XCDs: XCD k owns z tiles k, k + 8, ...; x runs fastest, then y (whole planes of tiles). The default
@@ -373,6 +377,7 @@ namespace
             by = (yb / grp) * (8u * grp) + xcd * grp + yb % grp;
             return bz < g.ntz && by < g.nty;
         }
+#ifdef PARIS_HIP_EXPERIMENTS
         if(g.order == 12u)
         {
             // order 8 applied to one chunk of zchunk z tiles after the other: XCD k owns the band k of y tiles; x runs fastest,
@@ -407,6 +412,7 @@ namespace
             by = xcd * band + yb;
             return bz < g.ntz && by < g.nty;
         }
+#endif
         if(g.order == 5u)
         {
             const uint32_t per = (total + 7u) / 8u;

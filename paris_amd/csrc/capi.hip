@@ -1153,9 +1153,11 @@ extern "C" int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, siz
         return rc;
     if(d_dst == nullptr || h_src == nullptr)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+#ifdef PARIS_HIP_EXPERIMENTS
     static const bool serial = [] { const char* e = std::getenv("PARIS_HIP_UPLOAD_STREAM"); return e != nullptr && e[0] == '0'; }();
     if(serial) // diagnostic: PARIS_HIP_UPLOAD_STREAM=0 keeps the copy on the compute stream (A/B of the overlap)
         return paris_hip_memcpy_projection_h2d(ctx, d_dst, d_pitch, h_src, h_pitch, dim_x, dim_y);
+#endif
     if(int rc = paris_hip_ensure_upload_stream(ctx))
         return rc;
     if(int rc = paris_hip_projection_guard(ctx, d_dst, d_pitch * dim_y, ctx->upload_stream, true))

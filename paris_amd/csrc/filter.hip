@@ -192,6 +192,7 @@ namespace
     // A stage's twiddle is base_t * (a 16th root of unity): base_t comes from the table (one load per stage and
     // thread), the roots are compile-time constants.
     // ------------------------------------------------------------------------------------------------------------
+#ifdef PARIS_HIP_EXPERIMENTS // the first radix-16 kernel (twiddles formed per stage): superseded by filter_fused.hip; cross-checks and tools only
     __device__ __forceinline__ float2 root16(int m) // exp(-2 pi i m / 16), m in [0, 8)
     {
         constexpr float c[8] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
@@ -414,6 +415,8 @@ namespace
         return PARIS_HIP_SUCCESS;
     }
 
+#endif // PARIS_HIP_EXPERIMENTS
+
     inline bool is_pow2(uint32_t v) { return v != 0 && (v & (v - 1)) == 0; }
 
     inline uint32_t ilog2(uint32_t v)
@@ -596,6 +599,7 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
     }
     if(int rc = paris_hip_flush_pending_weight(ctx))
         return rc;
+#ifdef PARIS_HIP_EXPERIMENTS
     if(ctx->filter_variant != 1 && log2n >= 10u)
     {
         int rc = PARIS_HIP_SUCCESS;
@@ -613,6 +617,7 @@ extern "C" int paris_hip_apply_filter(paris_hip_ctx* ctx, float* d_p, size_t pit
             return rc2;
         return paris_hip_finish(ctx);
     }
+#endif // (product build: a K this ctx did not make, or a length below 1024, runs the radix-2 kernel)
     hipLaunchKernelGGL(apply_filter_kernel, dim3((dim_y + 1u) / 2u), dim3(threads_for(filter_size)),
                        filter_size * sizeof(float2), ctx->stream, d_p, pitch_f, dim_x, dim_y, d_k, plan->d_twiddle, log2n);
     if(int rc = paris_hip_note_projection_use(ctx, d_p, pitch * dim_y))
@@ -720,6 +725,10 @@ extern "C" int paris_hip_set_filter_variant(paris_hip_ctx* ctx, int variant)
 {
     if(ctx == nullptr || variant < 0 || variant > 2)
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
+#ifndef PARIS_HIP_EXPERIMENTS
+    if(variant == 2) // the first radix-16 kernel lives in the experiments build only
+        return PARIS_HIP_ERROR_UNSUPPORTED;
+#endif
     if(int rc = paris_hip_flush_pending_weight(ctx))
         return rc;
     ctx->filter_variant = variant;

@@ -21,6 +21,9 @@
 //   * K is read in the order the fused middle pass holds the frequencies (one 16-float run per thread) from a permuted
 //     copy made once per filter, instead of 16 scattered loads per thread;
 //   * optionally the last pass stores IEEE half pixels into a second buffer (BASELINE config 5) instead of fp32 in place.
+#if (defined(PARIS_FILTER_TIMING_NO_COMPUTE) || defined(PARIS_FILTER_TIMING_NO_MEMORY)) && !defined(PARIS_HIP_EXPERIMENTS)
+#error "the timing-only switches compute WRONG results: they exist in the experiments build only (make EXPERIMENTS=1)"
+#endif
 #include "paris_hip_internal.h"
 #include "ieee_lean.h"
 

@@ -50,6 +50,18 @@ def volume_to_host(be, d_v):
     return h.buf
 
 
+def product_refuses(call, *args):
+    """Kernels, tile orders and switches that lost their A/B runs are compiled into the experiments build only (make EXPERIMENTS=1,
+    PARIS_HIP_LIBRARY=.../libparis_hip_experiments.so: tests/test_gpu_experiments_build.py runs these tests against it). Against the
+    product library the setter must answer PARIS_HIP_ERROR_UNSUPPORTED -- then there is nothing more to test: returns True."""
+    if _lib.has_experiments():
+        return False
+    with pytest.raises(_lib.ParisHipError) as e:
+        call(*args)
+    assert e.value.status == _lib.ERROR_UNSUPPORTED
+    return True
+
+
 def rel_l2(a, b):
     a = a.astype(np.float64)
     b = b.astype(np.float64)
@@ -152,9 +164,11 @@ def test_apply_filter(be, oracle, n_row, n_col, variant):
     tau = 0.2
     p = oracle.lcg_projection(n_row, n_col, 11) - np.float32(0.25)
     want = oracle.apply_filter(p.copy(), oracle.make_filter(fs, tau), fs)
+    if variant == 2 and product_refuses(be.set_filter_variant, 2):
+        return
     d_p = to_device(be, p)
     k = be.make_filter(fs, tau)
-    be.set_filter_variant(variant)  # 0: radix-16 passes with table twiddles (N >= 1024), 1: radix-2 in LDS, 2: first radix-16 kernel
+    be.set_filter_variant(variant)  # 0: radix-16 passes with table twiddles (N >= 1024), 1: radix-2 in LDS, 2: first radix-16 kernel (experiments build)
     try:
         be.apply_filter(d_p, k, fs, n_col)
     finally:
@@ -427,6 +441,8 @@ def assert_bit_equal(got, want):
 def test_backproject_kat_full_bit_exact(be, oracle, kat_golden, variant):
     det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
     vg = B.calculate_volume_geometry(det)
+    if variant == 3 and product_refuses(be.set_backproject_variant, 3):   # the slice kernel
+        return
     be.set_backproject_variant(variant)
     try:
         got = hip_backproject_all(be, kat_golden["filtered"], det, vg, (61, 67, 67))
@@ -468,6 +484,8 @@ def test_backproject_every_kernel_shape_bit_exact(be, oracle, tuning):
     ovg = oracle.VolumeGeometry(72, 40, 45, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
     projs = [oracle.lcg_projection(96, 80, i) - np.float32(0.5) for i in range(9)]
     want = oracle_backproject_all(oracle, projs, odet, ovg, (45, 40, 72))
+    if tuning.get("unroll", 0) > 2 and product_refuses(lambda: be.set_backproject_tuning(**tuning)):
+        return
     be.set_backproject_variant(2)
     be.set_backproject_tuning(**tuning)
     try:
@@ -493,6 +511,8 @@ def test_backproject_every_tile_order_bit_exact(be, oracle, order, tz, dims):
     full_z = dims[0] + 20
     vg = B.VolumeGeometry(dims[2], dims[1], full_z, nat.l_vx_x * 0.5, nat.l_vx_x * 0.35, nat.l_vx_x * 0.25)
     ovg = oracle.VolumeGeometry(dims[2], dims[1], full_z, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    if order in (0, 1, 8, 9, 12) and product_refuses(be.set_backproject_order, order, -1):
+        return
     projs = [oracle.lcg_projection(96, 80, i) - np.float32(0.5) for i in range(3)]
     want = oracle_backproject_all(oracle, projs, odet, ovg, dims, v_offset=13)
     be.set_backproject_tuning(tz=tz)
@@ -522,7 +542,10 @@ def test_deep_volume_nesting_on_small_volumes():
     nesting forced on their small volumes."""
     import subprocess
     import sys
-    env = dict(os.environ, PARIS_TILE_NEST="2")
+    # (PARIS_TILE_NEST is an A/B switch of the experiments build; the product picks the nesting by volume depth alone -- its deep
+    # nesting meets the oracle on deep volumes in tests/test_gpu_full_volume.py)
+    env = dict(os.environ, PARIS_TILE_NEST="2", PARIS_HIP_LIBRARY=_lib.EXPERIMENTS_LIB_PATH)
+    assert os.path.exists(_lib.EXPERIMENTS_LIB_PATH), "build it: make -C paris_amd/csrc EXPERIMENTS=1"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "every_tile_order", "-p", "no:cacheprovider"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
@@ -539,6 +562,8 @@ def test_backproject_two_pass_variant_bit_exact(be, oracle, tz, order, unroll):
     ovg = oracle.VolumeGeometry(260, 170, 120, vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
     roi, oroi = B.RegionOfInterest(20, 220, 10, 160, 5, 100), oracle.RegionOfInterest(20, 220, 10, 160, 5, 100)
     dims = (60, 150, 200)
+    if product_refuses(be.set_backproject_variant, 5):
+        return
     projs = [oracle.lcg_projection(96, 80, i) - np.float32(0.5) for i in range(3)]
     want = oracle_backproject_all(oracle, projs, odet, ovg, dims, v_offset=17, roi=oroi)
     be.set_backproject_variant(5)
@@ -614,6 +639,9 @@ def test_backproject_slice_kernel_shapes_bit_exact(be, oracle, shape, lds_bytes)
     dims = (45, 42, 72)  # z, y, x: 72 = 64 + 8, 42 rows, 45 slices
     vg = B.VolumeGeometry(dims[2], dims[1], dims[0], nat.l_vx_x * 1.3, nat.l_vx_x * 2.0, nat.l_vx_x * 1.7)
     ovg = oracle.VolumeGeometry(dims[2], dims[1], dims[0], vg.l_vx_x, vg.l_vx_y, vg.l_vx_z)
+    if product_refuses(be.set_backproject_slice_shape, *shape):
+        assert product_refuses(be.set_backproject_variant, 3)
+        return
     projs = [oracle.lcg_projection(96, 80, i) - np.float32(0.5) for i in range(5)]
     want = oracle_backproject_all(oracle, projs, odet, ovg, dims)
     be.set_backproject_variant(3)
@@ -1907,7 +1935,12 @@ def test_backproject_random_geometries_bit_exact(be, oracle, seed):
     # volumes are small: without this the band orders 8 / 9 / 12 and shallow tiles would only be fuzzed at full size)
     forced = seed % 2 == 1
     if forced:
-        be.set_backproject_order(int(rng.choice([0, 1, 5, 8, 9, 12, 14, 15, 16, 17, 18])), -1)
+        # (the product build has orders 5 and 14 .. 18; the experiments build adds the ones that lost: the draw is made either way, so
+        # that both builds see the same geometries)
+        drawn = int(rng.choice([0, 1, 5, 8, 9, 12, 14, 15, 16, 17, 18]))
+        if not _lib.has_experiments() and drawn in (0, 1, 8, 9, 12):
+            drawn = {0: 5, 1: 14, 8: 15, 9: 16, 12: 17}[drawn]
+        be.set_backproject_order(drawn, -1)
         be.set_backproject_tuning(tz=int(rng.choice([2, 5, 8, 16])))
     try:
         d_v = be.make_volume_device(dims[2], dims[1], dims[0])

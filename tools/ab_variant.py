@@ -8,6 +8,9 @@ import statistics
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# this tool turns knobs that only the experiments build compiles in (make -C paris_amd/csrc EXPERIMENTS=1)
+os.environ.setdefault("PARIS_HIP_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "paris_amd", "lib",
+                                                          "libparis_hip_experiments.so"))
 import numpy as np  # noqa: E402
 
 from paris_amd import backend as B  # noqa: E402
