@@ -144,3 +144,57 @@ def test_config5_uncropped_slab(oracle):
         del t_a, t_b
         abe.free(v_a)
         abe.free(v_b)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PARIS_FUZZ_PLANES", "4"))))
+def test_random_geometries_on_large_planes(oracle, seed):
+    """the paths a launch takes only on planes beyond 1024^2 -- 16-slice tiles with ONE slice in flight at four
+    workgroups per CU and the deep nesting of the dealt order from 257 slices (odd seeds: 257 .. 700 slices), 8-slice tiles up to
+    256 slices (even seeds: 30 .. 256) -- on seeded random geometries (detector size and pitch, offsets, cone, anisotropic voxels,
+    slab offset; every third seed an unaligned row length: narrower lanes), the default path with the skip on, single launches and
+    the fused batch, EVERY voxel against the oracle. PARIS_FUZZ_PLANES=n draws n seeds (the round's fuzz campaign: 40)."""
+    import torch
+    rng = np.random.default_rng(77000 + seed)
+    n_row, n_col = int(rng.integers(300, 900)), int(rng.integers(200, 700))
+    l_r, l_c = float(rng.choice([0.1, 0.2, 0.127, 0.4])), float(rng.choice([0.1, 0.2, 0.25]))
+    d_so, d_od = float(rng.uniform(150, 600)), float(rng.uniform(50, 600))
+    g = (n_row, n_col, l_r, l_c, float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)), d_so, d_od, float(rng.uniform(0.5, 40)))
+    det, odet = B.DetectorGeometry(*g), oracle.DetectorGeometry(*g)
+    nat = B.calculate_volume_geometry(det)
+    dx, dy = int(rng.integers(1028, 1500)), int(rng.integers(1026, 1400))
+    dx = dx if seed % 3 == 2 else (dx + 3) // 4 * 4                      # (unaligned rows every third seed)
+    dz = int(rng.integers(257, 700)) if seed % 2 else int(rng.integers(30, 257))
+    assert dx * dy > (1 << 20)
+    full_z = dz + int(rng.integers(0, 60))
+    v_offset = full_z - dz
+    scale = [float(nat.l_vx_x * n_row / dx * rng.uniform(0.7, 1.3)), float(nat.l_vx_x * n_row / dy * rng.uniform(0.7, 1.3)),
+             float(nat.l_vx_z * n_col / full_z * rng.uniform(0.6, 1.2))]
+    half_diag = 0.5 * np.hypot(dx * scale[0], dy * scale[1])
+    if half_diag > 0.8 * d_so:
+        scale[0] *= 0.8 * d_so / half_diag
+        scale[1] *= 0.8 * d_so / half_diag
+    vg, ovg = B.VolumeGeometry(dx, dy, full_z, *scale), oracle.VolumeGeometry(dx, dy, full_z, *scale)
+    angles = [float(rng.uniform(0, 360)) for _ in range(3)]
+    projs = [oracle.lcg_projection(n_row, n_col, 50 * seed + i) - np.float32(0.5) for i in range(3)]
+    want = np.zeros((dz, dy, dx), np.float32)
+    for i, p in enumerate(projs):
+        s, c, ds, dt = oracle.backproject_constants(odet, i, True, angles[i])
+        oracle.backproject(want, p, v_offset, odet, ovg, s, c, ds, dt, None)
+    dev = torch.device("cuda", 0)
+    with B.Backend(0, stream=torch.cuda.current_stream(dev).cuda_stream, synchronous=False) as abe:
+        stack = torch.from_numpy(np.stack(projs)).to(dev)
+        v_a = abe.make_volume_device(dx, dy, dz)
+        v_b = abe.make_volume_device(dx, dy, dz)
+        for i in range(3):
+            p = abe.wrap_projection(stack[i].data_ptr(), n_row * 4, n_row, n_col, idx=i, phi=angles[i], owner=stack)
+            B.backproject(abe, p, v_a, v_offset, det, vg, True, False, None)
+        sc = [B.stage_angle(det, i, True, angles[i]) for i in range(3)]
+        abe.backproject_batch(stack.data_ptr(), n_row * 4, n_row * n_col * 4, 3, n_row, n_col, v_b, v_offset, det, vg, False, None,
+                              [s for s, _ in sc], [c for _, c in sc], det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
+        abe.synchronize()
+        w = torch.from_numpy(want).to(dev)
+        assert torch.equal(device_view(torch, v_a, dev).view(torch.int32), w.view(torch.int32)), (seed, "single launches", dx, dy, dz)
+        assert torch.equal(device_view(torch, v_b, dev).view(torch.int32), w.view(torch.int32)), (seed, "fused batch", dx, dy, dz)
+        assert int(torch.count_nonzero(w)) > 0
+        abe.free(v_a)
+        abe.free(v_b)
