@@ -93,7 +93,7 @@ typedef struct paris_hip_ctx paris_hip_ctx;
  *      src/openmp/backend.h:87-89) -------------------------------------------------------------------- */
 /* Environment switches (diagnostics, read once per process): PARIS_HIP_VIRTUAL_DEVICES=k reports k device handles
  * mapped round-robin onto the physical GPUs (exercises the one-thread-per-device driver on a one-GPU box);
- * PARIS_HIP_UPLOAD_STREAM=0 keeps paris_hip_upload_projection on the compute stream (A/B of the overlap). */
+ * PARIS_HIP_UPLOAD_STREAM=0 keeps paris_hip_upload_projection on the compute stream (A/B of the overlap; experiments build only). */
 int paris_hip_device_count(int* count);
 
 /* Creates the per-device state. `stream` is a hipStream_t to enqueue on (e.g. the caller's torch stream),
@@ -138,7 +138,10 @@ int paris_hip_memcpy_projection_h2d(paris_hip_ctx* ctx, float* d_dst, size_t d_p
                                     size_t h_pitch, uint32_t dim_x, uint32_t dim_y);
 /* Extension: the same host -> device copy on a dedicated upload stream of the ctx, with the compute stream made to wait
  * for it (hipStreamWaitEvent): the transfer overlaps kernels already queued. Use pinned host memory, and do not
- * refill h_src or overwrite d_dst before the work that reads them has passed a fence; at most 16 uploads in flight. */
+ * refill h_src or overwrite d_dst before the work that reads them has passed a fence; at most 16 uploads in flight. An upload into
+ * a buffer of paris_hip_malloc_projection that no call of this API has touched since it was handed out starts at once, whatever the
+ * compute stream still holds: work the CALLER enqueued on such a buffer itself (own kernels on the ctx stream) must be complete
+ * before the upload -- the library sees only its own entry points. */
 int paris_hip_upload_projection(paris_hip_ctx* ctx, float* d_dst, size_t d_pitch, const float* h_src, size_t h_pitch,
                                 uint32_t dim_x, uint32_t dim_y);
 int paris_hip_memcpy_projection_d2h(paris_hip_ctx* ctx, float* h_dst, size_t h_pitch, const float* d_src,

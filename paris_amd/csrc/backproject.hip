@@ -767,7 +767,7 @@ static int backproject_impl(paris_hip_ctx* ctx, const void* d_p, bool f16, size_
         // config 5 0.7424 -> 0.7640; with five workgroups 0.780, with three 0.705, two slices in flight at four (rounds 1-3) 0.785,
         // a prefetched next slice 0.763. This stream runs fastest with FEW requests in flight -- as many as hide the latency and no
         // more: what sets its rate is the order in which the tiles' requests reach DRAM (profiles/r04_ab_tile_occupancy.txt,
-        // r04_ab_tile_prefetch.txt). 8-slice tiles (slabs up to 512 slices, planes up to 1024^2) keep one slice at five: 0.765
+        // r04_ab_tile_prefetch.txt). 8-slice tiles (slabs up to 256 slices, planes up to 1024^2) keep one slice at five: 0.765
         // against 0.711 at four.
         const bool deep_big = g.tz == 16u && ctx->bp_tz == 0u && static_cast<uint64_t>(v_dim_x) * v_dim_y > (1ull << 20);
         if(deep_big && ctx->bp_unroll == 0 && ctx->bp_lds_bytes == 0u && vx == 4)

@@ -33,6 +33,8 @@ run python bench.py --steps 20 --warmup 5 --workload c2 --cpu-budget 0 --cpu-c1 
 run python bench.py --steps 20 --warmup 5 --workload c1 --cpu-budget 0 --cpu-c1 0 > $out/${tag}_bench_c1_1gpu.json
 run python bench.py --steps 20 --warmup 5 --workload c1 --graph 1 --cpu-budget 0 --cpu-c1 0 > $out/${tag}_bench_c1_graph_1gpu.json
 run python bench.py --steps 20 --warmup 5 --workload c5 --cpu-budget 0 --cpu-c1 0 > $out/${tag}_bench_c5_1gpu.json
+# config 5 without the ROI crop: rank 3's 4096 x 4096 x 512 slab of the 8-GPU job over the whole 4096^3 grid, 360 launches over the circle
+run python bench.py --steps 10 --warmup 1 --workload c5u --as-world 8 --as-rank-base 3 --batch 36 --spread 1 --cpu-budget 0 --cpu-c1 0 > $out/${tag}_bench_c5_uncropped_slab.json
 echo "benches done" >&2
 # 3. the same default command under the profiler (kernel trace only)
 run rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 5 --cpu-budget 0 --cpu-c1 0 --live-traffic 0 > $out/${tag}_bench_under_rocprof_c3.json
@@ -51,6 +53,12 @@ echo "kernel stats done" >&2
 } > $out/${tag}_demo_paris_hip_mirror.txt 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OLDPWD/$out/demo_trace -- $OLDPWD/paris_amd/host/demo/paris_hip_demo 1024 1024 0.2 0.2 0 0 500 500 0.5 720 lcg /dev/null --cycle 48 --no-out > /dev/null 2>&1 )
 { echo "# rocprofv3 --kernel-trace --memory-copy-trace -- paris_hip_demo 1024 1024 ... 720 lcg (PARIS's loop through paris::hip, whole circle): tools/timeline.py"; python tools/timeline.py $out/demo_trace; } > $out/${tag}_demo_timeline_1024.txt 2>&1
+# the same loop with the time of every call of one iteration, for the default build (by reference, in-place group filter), the
+# snapshotting build and the filter-at-once build; and the device timeline of the 360 x 512^2 -> 512^3 job
+bash tools/mirror_split.sh > $out/${tag}_mirror_split.txt 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OLDPWD/$out/demo_trace512 -- $OLDPWD/paris_amd/host/demo/paris_hip_demo 512 512 0.2 0.2 0 0 500 500 1.0 360 lcg /dev/null --cycle 48 --no-out > /dev/null 2>&1 )
+{ echo "# rocprofv3 --kernel-trace --memory-copy-trace -- paris_hip_demo 512 512 ... 360 lcg (PARIS's loop through paris::hip, whole circle into 512^3): tools/timeline.py"; python tools/timeline.py $out/demo_trace512; } > $out/${tag}_demo_timeline_512.txt 2>&1
+rm -rf $out/demo_trace512
 echo "demo done" >&2
 rm -rf $out/demo_trace $out/stats $out/prof_fetch $out/prof_write $out/pmc_sq_a $out/pmc_sq_b $out/pmc_w1 $out/quick.json
 ls -la $out >&2
