@@ -311,3 +311,43 @@ def test_asynchronous_validation_changes_no_bit(oracle):
     assert np.array_equal(bits(got_async), bits(want))
     assert np.array_equal(bits(run(False, False)), bits(want))
     assert np.array_equal(bits(run(True, True)), bits(run(False, True)))
+
+
+@pytest.mark.parametrize("depth", [3, 48])
+def test_half_precision_projections_by_reference(oracle, depth):
+    """BASELINE config 5's storage through the same mechanism: the half-precision copy of each projection lives in a buffer of the
+    projection allocator, is backprojected (deferred, by reference) and freed at once, like the fp32 frame it came from. Equal to
+    the oracle fed the half-rounded frames, bit for bit; one frame is converted again into the SAME half buffer while the pending
+    group still refers to it (the conversion's destination is guarded: the group runs first)."""
+    det, odet = B.DetectorGeometry(*KAT), oracle.DetectorGeometry(*KAT)
+    vg, ovg = B.calculate_volume_geometry(det), oracle.calculate_volume_geometry(odet)
+    n_proj = 20
+    frames = [(oracle.lcg_projection(64, 48, i) - np.float32(0.5)) * np.float32(3.0) for i in range(n_proj)]
+    want = np.zeros((vg.dim_z, vg.dim_y, vg.dim_x), np.float32)
+    order = []
+    for i in range(n_proj):
+        order.append(i)
+        if i == 7:
+            order.append(8)   # (projection 8's pixels, at angle 7's successor: the re-converted buffer below)
+    with B.Backend(0, synchronous=False) as abe:
+        abe.set_backproject_deferral(depth)
+        abe.set_backproject_references(True)
+        d_v = abe.make_volume_device(vg.dim_x, vg.dim_y, vg.dim_z)
+        for i in range(n_proj):
+            d_p = abe.make_projection_device(64, 48)
+            upload(abe, d_p, frames[i])
+            h_ptr, h_pitch = abe.convert_projection_f16(d_p)
+            s, c = B.stage_angle(det, i)
+            abe.backproject_f16(h_ptr, h_pitch, 64, 48, d_v, 0, det, vg, False, None, s, c, det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
+            so, co, ds, dt = oracle.backproject_constants(odet, i)
+            oracle.backproject(want, frames[i].astype(np.float16).astype(np.float32), 0, odet, ovg, so, co, ds, dt)
+            if i == 7:
+                # the same half buffer refilled from another frame and backprojected again before it is freed
+                upload(abe, d_p, frames[8])
+                B._lib.check(abe._L.paris_hip_convert_projection_f16(abe._ctx, d_p.ptr, d_p.pitch, h_ptr, h_pitch, 64, 48), "convert")
+                abe.backproject_f16(h_ptr, h_pitch, 64, 48, d_v, 0, det, vg, False, None, s, c, det.delta_s * det.l_px_row, det.delta_t * det.l_px_col)
+                oracle.backproject(want, frames[8].astype(np.float16).astype(np.float32), 0, odet, ovg, so, co, ds, dt)
+            abe.free(h_ptr)
+            abe.free(d_p)
+        got = volume_to_host(abe, d_v)
+    assert np.array_equal(bits(got), bits(want))

@@ -289,3 +289,29 @@ def test_fast_path_row_weight_identity():
     rng = np.random.default_rng(1)
     v = (rng.random(10_000_000) * rng.choice([8, 100, 5000, 70000, 2 ** 20, 2 ** 24 - 2], 10_000_000)).astype(np.float32)
     assert mismatches(v) == 0
+
+
+def test_the_product_build_ships_no_experiments():
+    """two builds of one C ABI. The product library holds the kernels its launcher picks by itself; the slice
+    kernel, the two-pass variant, the first radix-16 filter kernel and the getenv A/B switches exist only in the experiments build
+    (make EXPERIMENTS=1), which exports the same symbols; a PARIS_*TIMING* macro (wrong results, timing only) cannot be compiled
+    into the product at all."""
+    import ctypes
+    import subprocess
+    product = os.path.join(ROOT, "paris_amd", "lib", "libparis_hip.so")
+    experiments = _lib.EXPERIMENTS_LIB_PATH
+    assert os.path.exists(experiments), "make -C paris_amd/csrc EXPERIMENTS=1 (__graft_entry__.build() does)"
+    p, x = ctypes.CDLL(product), ctypes.CDLL(experiments)
+    assert p.paris_hip_has_experiments() == 0 and x.paris_hip_has_experiments() == 1
+    for name in _lib.SIGNATURES:
+        getattr(x, name)
+    pb, xb = open(product, "rb").read(), open(experiments, "rb").read()
+    for marker in (b"bp_slice_kernel", b"bp_column_state_kernel", b"apply_filter_r16_kernel", b"PARIS_TILE_NEST", b"PARIS_FUSED_XFAST",
+                   b"PARIS_HIP_UPLOAD_STREAM"):
+        assert marker not in pb and marker in xb, marker
+    assert len(pb) < 0.8 * len(xb)
+    for src, macro in (("backproject_fused.hip", "PARIS_TIMING_ONLY_STAGE_ONCE"), ("filter_fused.hip", "PARIS_FILTER_TIMING_NO_MEMORY")):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-D" + macro, "-I" + os.path.join(ROOT, "include"),
+                            "-I" + os.path.join(ROOT, "paris_amd", "csrc"), os.path.join(ROOT, "paris_amd", "csrc", src)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "experiments build only" in r.stderr, (src, r.stderr[-500:])
