@@ -591,6 +591,12 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # where this invocation's wall time goes, leg by leg (reported as `legs_seconds`: the driver's one command must stay within minutes)
+    marks = [("start", time.perf_counter())]
+
+    def mark(name):
+        marks.append((name, time.perf_counter()))
+
     # roofline.traffic, measured live: child processes under the profiler, before this process initialises the GPU
     live = {}
     under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
@@ -601,6 +607,7 @@ def main():
             tail += ["--" + name.replace("_", "-"), str(getattr(args, name))]
         live = live_counters(tail, fused_batch=max(2, min(64, args.fused_batch)))
 
+    mark("live_counter_passes")
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -800,6 +807,7 @@ def main():
 
     barrier()
     torch.cuda.synchronize()
+    mark("setup_and_warmup")
     t0 = time.perf_counter()
     if graphs is not None:
         for g in graphs:
@@ -813,6 +821,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    mark("timed_region")
 
     if graphs is None:
         kernel_ms = be.backproject_timing_collect()
@@ -833,6 +842,7 @@ def main():
         be.backproject_timing_arm(1)
         del launched[-len(spread):]
 
+    mark("skip_off_step")
     # ---- extension, outside the headline: the same step with ONE fused launch per batch (paris_hip_backproject_batch)
     fused = None
     if args.fused_steps > 0:
@@ -905,6 +915,7 @@ def main():
             fused["deferred_host_seconds"] = td_host
             fused["deferred_projections"] = len(starts) * fb
 
+    mark("fused_and_deferred_legs")
     # ---- the job's one collective (north star: "no RCCL collective needed beyond a final gather"), timed on its own
     gather = None
     # (N = 1 under torch.distributed.run: only when the slabs are asked for -- it exercises dist.gather and the float64
@@ -1073,11 +1084,13 @@ def main():
             out["config"]["per_rank"] = per_rank
             # the PMC traffic figure is of ONE kernel build: every rank reports the build it ran
             out["roofline"]["kernel_source_sha16_by_rank"] = [r["kernel_source_sha16"] for r in per_rank]
+        mark("final_gather_and_report")
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
             out["cpu_baseline"]["cpu_model"] = cpu_model()
             if args.cpu_c1:
                 out["cpu_baseline_c1"] = cpu_baseline_c1()
+        mark("cpu_baselines")
         if ((args.workloads or args.paris_loop) and world == 1 and dist is None and args.workload == "c3" and args.slices == 0 and args.batch == 0
                 and not under_profiler):
             # the headline is complete: free its 32 GiB slab and stacks, then the other configs, one child at a time
@@ -1089,8 +1102,13 @@ def main():
                 tail += ["--" + name.replace("_", "-"), str(getattr(args, name))]
             if args.workloads:
                 out["workloads"] = other_workloads(tail)
+                mark("workloads_children")
             if args.paris_loop:
                 out["paris_loop"] = paris_loop()
+                mark("paris_loop_children")
+        mark("end")
+        out["legs_seconds"] = {b[0]: round(b[1] - a[1], 3) for a, b in zip(marks, marks[1:]) if b[0] != "end" or b[1] - a[1] > 0.05}
+        out["legs_seconds"]["total"] = round(marks[-1][1] - marks[0][1], 3)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 

@@ -1081,7 +1081,17 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
     // ring's row pitch -- the group reads the buffer itself. Until the group has been launched the library answers for the buffer:
     // paris_hip_free() marks it, every other call that touches it launches the group first (paris_hip_projection_guard).
     paris_hip_ctx::proj_alloc* mine = nullptr;
-    if(ctx->defer_refs != 0 && p_pitch == ctx->defer_pitch && !(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS))
+    bool by_reference = ctx->defer_refs != 0 && p_pitch == ctx->defer_pitch && !(ctx->flags & PARIS_HIP_CTX_SYNCHRONOUS);
+    if(by_reference && !ctx->owns_stream)
+    {
+        // a caller's stream may be being captured into a graph: the group's completion event could then never be queried, and a
+        // replay would read buffers long recycled -- such calls keep their snapshots
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if(hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+            by_reference = false;
+        (void)hipGetLastError();
+    }
+    if(by_reference)
     {
         auto a = ctx->proj_allocs.find(const_cast<void*>(d_p));
         if(a != ctx->proj_allocs.end() && a->second.bytes >= p_pitch * static_cast<size_t>(p_dim_y))

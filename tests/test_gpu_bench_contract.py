@@ -55,6 +55,10 @@ def test_single_gpu_line():
     c1 = d["cpu_baseline_c1"]
     assert c1["kind"] == "port" and c1["cores"] >= 1 and c1["value"] > 0 and c1["backproject_s"] > 0 and c1["cpu_model"]
     assert abs(c1["value"] - 256.0 ** 3 * 360 / c1["backproject_s"] / 1e9) < 1e-9 * c1["value"]
+    # where the invocation's wall time went, leg by leg
+    legs = d["legs_seconds"]
+    assert legs["total"] > legs["timed_region"] > 0 and "cpu_baselines" in legs and "setup_and_warmup" in legs
+    assert abs(sum(v for k, v in legs.items() if k != "total") - legs["total"]) < 0.2
 
 
 def test_two_rank_rehearsal():
