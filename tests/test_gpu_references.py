@@ -351,3 +351,34 @@ def test_half_precision_projections_by_reference(oracle, depth):
             abe.free(d_p)
         got = volume_to_host(abe, d_v)
     assert np.array_equal(bits(got), bits(want))
+
+
+def test_out_of_memory_drains_the_pools_and_retries(oracle):
+    """buffers parked in the projection pool are memory too. With the device nearly full (a torch tensor holds all but
+    ~3 GiB) and ~4 GiB parked in the pool, a 5 GiB volume -- then a projection buffer of a new size -- can only be allocated after the
+    pool has given its buffers back: hipErrorOutOfMemory drains it and the allocation is tried once more."""
+    import torch
+    with B.Backend(0, synchronous=False) as abe:
+        bufs = [abe.make_projection_device(16384, 4096 + 16 * (i // 8)) for i in range(16)]   # 16 x ~256 MiB, two size classes
+        for b in bufs:
+            abe.free(b)                                                                       # parked: ~4 GiB
+        abe.synchronize()
+        torch.cuda.synchronize()
+        free, _ = torch.cuda.mem_get_info(0)
+        hog = torch.empty(int(free - (3 << 30)), dtype=torch.uint8, device="cuda:0")          # leaves ~3 GiB outside the pool
+        free_now, _ = torch.cuda.mem_get_info(0)
+        assert free_now < (4 << 30)
+        d_v = abe.make_volume_device(1024, 1024, 1280)                                        # 5 GiB: needs the parked memory
+        assert d_v.ptr
+        abe.free(d_v)
+        # the pool is empty now: fill it again and ask for a projection buffer of another size that does not fit beside it
+        bufs = [abe.make_projection_device(16384, 4096) for _ in range(8)]
+        for b in bufs[1:]:
+            abe.free(b)
+        abe.synchronize()
+        big = abe.make_projection_device(16384, 4096 * 12)                                    # 3 GiB
+        assert big.ptr
+        abe.free(big)
+        abe.free(bufs[0])
+        del hog
+    torch.cuda.empty_cache()
