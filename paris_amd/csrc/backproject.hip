@@ -922,6 +922,7 @@ int paris_hip_launch_deferred(paris_hip_ctx* ctx)
             // the next flush; the caller sees the error
             ctx->defer_count = 0;
             ctx->defer_uses_ring = false;
+            (void)hipStreamSynchronize(ctx->stream); // filter launches that did go out may still run in buffers that are given back below
             ctx->stream = caller_stream;
             (void)paris_hip_release_group_references(ctx, 0u);
             return wrc;
