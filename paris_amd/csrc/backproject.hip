@@ -997,6 +997,17 @@ int paris_hip_flush_deferred(paris_hip_ctx* ctx)
     return PARIS_HIP_SUCCESS;
 }
 
+// how many calls the first group of a sequence waits for (then twice as many, ... until the depth)
+static uint32_t first_ramp()
+{
+#ifdef PARIS_HIP_EXPERIMENTS
+    static const uint32_t v = [] { const char* e = std::getenv("PARIS_DEFER_RAMP"); const int n = e ? std::atoi(e) : 0; return n > 0 ? static_cast<uint32_t>(n) : 8u; }(); // A/B switch
+    return v;
+#else
+    return 8u;
+#endif
+}
+
 static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size_t p_pitch, uint32_t p_dim_x, uint32_t p_dim_y, float* d_v,
                              uint32_t v_dim_x, uint32_t v_dim_y, uint32_t v_dim_z, uint32_t v_offset,
                              const paris_detector_geometry* det_geo, const paris_volume_geometry* vol_geo, int enable_roi,
@@ -1072,7 +1083,7 @@ static int defer_backproject(paris_hip_ctx* ctx, const void* d_p, bool f16, size
         ctx->key_delta_s = delta_s;
         ctx->key_delta_t = delta_t;
         ctx->key_valid = true;
-        ctx->defer_ramp = 8u; // a new sequence: its first groups are launched early
+        ctx->defer_ramp = first_ramp(); // a new sequence: its first groups are launched early
         ctx->defer_sin.assign(ctx->defer_depth, 0.f);
         ctx->defer_cos.assign(ctx->defer_depth, 0.f);
         ctx->defer_ptr.assign(ctx->defer_depth, nullptr);
@@ -1175,7 +1186,7 @@ extern "C" int paris_hip_set_backproject_deferral(paris_hip_ctx* ctx, uint32_t d
     // a sequence continued after this call starts over: its tables are sized for the new depth and its first groups are launched
     // early again
     ctx->key_valid = false;
-    ctx->defer_ramp = 8u;
+    ctx->defer_ramp = first_ramp();
     return PARIS_HIP_SUCCESS;
 }
 
