@@ -158,6 +158,8 @@ def other_workloads(common_tail):
         env.pop(k, None)
     plans = [
         ("c1", ["--workload", "c1", "--steps", "10", "--warmup", "2"]),
+        # config 1's step is launch bound (three launches of ~25 us of GPU work from Python): the same steps captured into hipGraphs
+        ("c1_hip_graph", ["--workload", "c1", "--steps", "10", "--warmup", "2", "--graph", "1"]),
         ("c2", ["--workload", "c2", "--steps", "10", "--warmup", "2"]),
         ("c4_slab_shape", ["--workload", "c3", "--slices", "256", "--steps", "20", "--warmup", "2"]),
         ("c5_sampled", ["--workload", "c5", "--steps", "10", "--warmup", "1", "--batch", "36", "--spread", "1"]),
@@ -187,7 +189,8 @@ def other_workloads(common_tail):
              "roofline": {"bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "unit": rf["unit"],
                           "frac_without_skip": rf.get("frac_without_skip"), "launches_timed": rf["launches_timed"]},
              "fused": d.get("fused_extension", {}).get("value"), "fused_kernel_ms_per_launch": d.get("fused_extension", {}).get("kernel_ms_per_launch"),
-             "deferred": d.get("deferred_boundary", {}).get("value"), "wall_seconds_of_the_child_run": time.perf_counter() - t0}
+             "deferred": d.get("deferred_boundary", {}).get("value"), "hip_graph": cfg.get("hip_graph", False),
+             "wall_seconds_of_the_child_run": time.perf_counter() - t0}
         if "frac_of_cache_resident_rate" in rf:
             e["roofline"]["frac_of_cache_resident_rate"] = rf["frac_of_cache_resident_rate"]
         out[name] = e

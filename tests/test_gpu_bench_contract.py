@@ -305,13 +305,14 @@ def test_default_run_reports_every_baseline_config():
     d = last_json_line(r.stdout)
     assert d["config"]["whole_job"] is True and d["config"]["projections_timed"] == 1440
     wl = d["workloads"]
-    assert sorted(wl) == ["c1", "c2", "c4_slab_shape", "c5_sampled", "c5_uncropped_slab"]
+    assert sorted(wl) == ["c1", "c1_hip_graph", "c2", "c4_slab_shape", "c5_sampled", "c5_uncropped_slab"]
     for name, e in wl.items():
         assert "error" not in e, (name, e)
         for key in ("value", "backproject_kernel_ms", "fused", "deferred", "ms_per_step", "projections_timed", "whole_job"):
             assert e[key] is not None, (name, key)
         assert e["value"] > 0 and e["fused"] > e["value"] and 0.3 < e["roofline"]["frac"] < 1.0
         assert e["roofline"]["frac_without_skip"] is not None
+    assert wl["c1_hip_graph"]["whole_job"] and wl["c1_hip_graph"]["value"] > 0.9 * wl["c1"]["value"]
     assert wl["c1"]["whole_job"] and wl["c2"]["whole_job"] and wl["c4_slab_shape"]["whole_job"] and not wl["c5_sampled"]["whole_job"]
     assert wl["c1"]["projections_timed"] == 360 and wl["c2"]["projections_timed"] == 720 and wl["c4_slab_shape"]["projections_timed"] == 1440
     assert wl["c5_sampled"]["projections_timed"] == 360 and wl["c5_sampled"]["dtype"] == "f16-in/f32"
