@@ -333,8 +333,11 @@ int paris_hip_flush(paris_hip_ctx* ctx);
  * pixels whenever anything looks at it through this API. The one thing the library cannot see is work the caller enqueues on
  * the ctx stream by itself: a caller whose own kernels write projection buffers after backprojecting them leaves this off (the
  * default; snapshots). Projections in memory the library did not allocate, row-band pointers into a buffer, other pitches and
- * calls made while a caller-supplied ctx stream is being captured into a graph are snapshotted as before (a group may mix both). paris::hip switches it on: PARIS's loop (src/main.cpp:98-105) allocates,
- * fills, backprojects and frees one buffer per projection (src/loader.cpp:28-33) and touches nothing outside the backend. */
+ * calls made while a caller-supplied ctx stream is being captured into a graph are snapshotted as before (a group may mix both).
+ * A caller that REFILLS one buffer for every projection gains nothing from it -- each refill finds the buffer referenced and launches
+ * the pending group, one projection per launch -- and keeps the snapshots. paris::hip switches it on: PARIS's loop
+ * (src/main.cpp:98-105) allocates, fills, backprojects and frees one buffer per projection (src/loader.cpp:28-33) and touches
+ * nothing outside the backend. */
 int paris_hip_set_backproject_references(paris_hip_ctx* ctx, int enable);
 /* What this ctx may keep allocated for projections of dim_x x dim_y pixels beside the volume, with its present deferral settings (the
  * rotation of paris_hip_malloc_projection buffers, the pending group's buffers or the snapshot ring): the reserve_bytes a driver
