@@ -577,7 +577,7 @@ def main():
     ap.add_argument("--as-rank-base", type=int, default=0)
     ap.add_argument("--block-checksums", type=int, default=0, help="N = 1: also report the float64 sum of each of this many z blocks "
                     "of the volume (the reference's split rule), i.e. the slab checksums an N-rank run of the same projections must reproduce")
-    ap.add_argument("--dist-timeout", type=float, default=120.0, help="seconds a rank waits in the rendezvous (init_process_group) "
+    ap.add_argument("--dist-timeout", type=float, default=240.0, help="seconds a rank waits in the rendezvous (init_process_group) "
                     "before it gives up: one dead rank ends the run instead of hanging the others until the caller's limit")
     ap.add_argument("--paris-loop", type=int, default=1, help="1 (default; N = 1, the whole config-3 job only): PARIS's own per-projection "
                     "loop through the C++ mirror (paris_hip_demo, child processes) is timed for four jobs and reported as `paris_loop`")
