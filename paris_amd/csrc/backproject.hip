@@ -53,25 +53,6 @@ namespace
     // Tile kernel (z-walk in time). 1-D grid over ntx * nty * ntz tiles of 64 x TY x g.tz voxels, TY = 4*VX.
     // Serves every alignment (VX = 1, 2, 4).
     // --------------------------------------------------------------------------------------------
-#ifdef PARIS_HIP_EXPERIMENTS // measured slower: only in the experiments build (make EXPERIMENTS=1)
-    // Two-pass variant, pass A: the z-invariant constants of every (x,y) column of the slab's plane for this projection,
-    // computed once instead of once per tile (src/openmp/backprojection.cpp:116-129,139): three planes factor / h / u.
-    template <bool FD>
-    __global__ void __launch_bounds__(256) bp_column_state_kernel(const BpParams g, float* __restrict__ st)
-    {
-        const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-        const uint32_t l = blockIdx.y;
-        if(k >= g.v_dim_x)
-            return;
-        const ColConst c = column_constants<FD>(g, g.k_off + k, g.l_off + l);
-        const size_t plane = static_cast<size_t>(g.v_dim_x) * g.v_dim_y;
-        const size_t at = static_cast<size_t>(l) * g.v_dim_x + k;
-        st[at] = c.factor;
-        st[plane + at] = c.h;
-        st[2u * plane + at] = c.u;
-    }
-
-#endif // PARIS_HIP_EXPERIMENTS
 #ifndef PARIS_TILE_MIN_WAVES
 #define PARIS_TILE_MIN_WAVES 1
 #endif
@@ -209,121 +190,9 @@ namespace
             walk(std::false_type{}); // some tap of this lane may leave the staged box: per-voxel check + global path
     }
 
-#ifdef PARIS_HIP_EXPERIMENTS // measured slower than the tile kernel: only in the experiments build
-    // --------------------------------------------------------------------------------------------
-    // Slice kernel (z across waves). A workgroup of NW waves owns a tile of 64 x (4*RPL) columns x NW slices; wave w
-    // updates slice w, so a thread issues its RPL 16-byte loads once, updates 4*RPL voxels and stores: the volume
-    // stream has the shape of the fastest plain sweep (tools/membench6.hip: 6.0 TB/s against 5.5 for the z-walk).
-    // The z-invariant column state that the tile kernel keeps in registers is computed once per workgroup (one
-    // thread per column) and shared through LDS as structure-of-arrays, read back as float4 per 4 columns.
-    // Needs dim_x % 4 == 0 and a 16-byte aligned volume. LDS: 8 * 64 * 4*RPL words of column state + the box.
-    // --------------------------------------------------------------------------------------------
-    constexpr uint32_t SLICE_STATE_ARRAYS = 8u;
-
-    template <int NW, int RPL, bool NT, bool FD>
-    __global__ void __launch_bounds__(NW * 64, 8) bp_slice_kernel(const BpParams g)
-    {
-        extern __shared__ __attribute__((aligned(16))) float lds[];
-        constexpr uint32_t TY = 4u * RPL;
-        constexpr uint32_t NCOL = 64u * TY;
-        float* c_factor = lds;
-        float* c_u = lds + NCOL;
-        float* c_wx1 = lds + 2u * NCOL;
-        float* c_wx2 = lds + 3u * NCOL;
-        float* c_ymax = lds + 4u * NCOL;
-        int* c_xoff = reinterpret_cast<int*>(lds + 5u * NCOL);
-        int* c_x1i = reinterpret_cast<int*>(lds + 6u * NCOL);
-        int* c_fast = reinterpret_cast<int*>(lds + 7u * NCOL);
-        float* lds_box = lds + SLICE_STATE_ARRAYS * NCOL;
-
-        const uint32_t tid = threadIdx.x;
-        const uint32_t lane = tid & 63u;
-        const uint32_t wave = tid >> 6;
-
-        uint32_t bx, by, bz;
-        if(!tile_of_block(g, blockIdx.x, bx, by, bz))
-            return;
-        const uint32_t k0 = bx * 64u;
-        const uint32_t l0 = by * TY;
-        const uint32_t m0 = bz * NW;
-        const uint32_t k1 = min(k0 + 63u, g.v_dim_x - 1u);
-        const uint32_t l1 = min(l0 + TY - 1u, g.v_dim_y - 1u);
-        const uint32_t m1 = min(m0 + NW - 1u, g.v_dim_z - 1u);
-
-        const Box box = tile_box(g, k0, k1, l0, l1, m0, m1, lane, g.lds_floats - SLICE_STATE_ARRAYS * NCOL);
-        stage_box(g, box, lds_box, wave, NW, lane);
-
-        // column state: thread t computes columns t, t + NW*64, ...; column c = cy * 64 + cx
-        const float z_first = g.z_base + static_cast<float>(g.m_off + m0) * g.l_vx_z;
-        const float z_last = g.z_base + static_cast<float>(g.m_off + m1) * g.l_vx_z;
-        for(uint32_t c = tid; c < NCOL; c += NW * 64u)
-        {
-            const uint32_t cx = c & 63u, cy = c >> 6;
-            const Column col = make_column<FD>(g, box, g.k_off + min(k0 + cx, k1), g.l_off + min(l0 + cy, l1), z_first, z_last);
-            c_factor[c] = col.factor;
-            c_u[c] = col.u;
-            c_wx1[c] = col.wx1;
-            c_wx2[c] = col.wx2;
-            c_ymax[c] = col.ymax;
-            c_xoff[c] = col.xoff;
-            c_x1i[c] = col.x1i;
-            c_fast[c] = col.fast ? 1 : 0;
-        }
-        __syncthreads();
-
-        const uint32_t m = m0 + wave;
-        if(m > m1)
-            return;
-        const uint32_t xq = lane & 15u, yy = lane >> 4;
-        const uint32_t k = k0 + xq * 4u;
-        if(k >= g.v_dim_x)
-            return;
-        const float z_m = g.z_base + static_cast<float>(g.m_off + m) * g.l_vx_z; // :118
-        float* vp = g.vol + (static_cast<size_t>(m) * g.v_dim_y + l0 + yy) * g.v_dim_x + k;
-        const size_t row4 = static_cast<size_t>(4u) * g.v_dim_x;
-
-        float4 acc[RPL];
-        bool all_fast = true;
-#pragma unroll
-        for(int r = 0; r < RPL; ++r)
-            if(l0 + yy + 4u * r < g.v_dim_y)
-            {
-                acc[r] = load_voxels<4, NT>(vp + r * row4);
-                const int4 f = *reinterpret_cast<const int4*>(c_fast + (yy + 4u * r) * 64u + xq * 4u);
-                all_fast = all_fast && ((f.x & f.y & f.z & f.w) != 0);
-            }
-        auto add = [&](auto fast_tag) {
-            constexpr bool FAST = decltype(fast_tag)::value;
-#pragma unroll
-            for(int r = 0; r < RPL; ++r)
-            {
-                if(l0 + yy + 4u * r >= g.v_dim_y)
-                    continue;
-                const uint32_t c = (yy + 4u * r) * 64u + xq * 4u;
-                const float4 f4 = *reinterpret_cast<const float4*>(c_factor + c);
-                const float4 u4 = *reinterpret_cast<const float4*>(c_u + c);
-                const float4 a4 = *reinterpret_cast<const float4*>(c_wx1 + c);
-                const float4 b4 = *reinterpret_cast<const float4*>(c_wx2 + c);
-                const float4 y4 = *reinterpret_cast<const float4*>(c_ymax + c);
-                const int4 o4 = *reinterpret_cast<const int4*>(c_xoff + c);
-                const int4 i4 = *reinterpret_cast<const int4*>(c_x1i + c);
-                acc[r].x += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.x, u4.x, a4.x, b4.x, y4.x, o4.x, i4.x, FAST, false, false});
-                acc[r].y += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.y, u4.y, a4.y, b4.y, y4.y, o4.y, i4.y, FAST, false, false});
-                acc[r].z += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.z, u4.z, a4.z, b4.z, y4.z, o4.z, i4.z, FAST, false, false});
-                acc[r].w += voxel_contribution<FD, FAST>(g, box, lds_box, z_m, Column{f4.w, u4.w, a4.w, b4.w, y4.w, o4.w, i4.w, FAST, false, false});
-            }
-        };
-        if(all_fast)
-            add(std::true_type{});
-        else
-            add(std::false_type{});
-#pragma unroll
-        for(int r = 0; r < RPL; ++r)
-            if(l0 + yy + 4u * r < g.v_dim_y)
-                store_voxels<4, NT>(vp + r * row4, acc[r]);
-    }
-
-#endif // PARIS_HIP_EXPERIMENTS
+#ifdef PARIS_HIP_EXPERIMENTS // kernels that were measured and lost (the two-pass variant's pass A, the slice kernel): experiments build only
+#include "experiments/bp_kernels.inc"
+#endif
     // --------------------------------------------------------------------------------------------
     // Cross-check kernel (variant 1): one thread per voxel, taps straight from global memory, the
     // reference's loop body verbatim in structure. Slow; used by tests to validate the tile kernel.
@@ -412,67 +281,9 @@ namespace
             launch_tile_unroll<VX, false, false>(g, unroll, stream);
     }
 
-#ifdef PARIS_HIP_EXPERIMENTS // the two-pass variant and the slice kernel's launchers
-    // two-pass variant (variant 5): pass A writes the column constants of the whole plane, pass B is the tile kernel reading them
-    template <int UNROLL, bool FD>
-    void launch_tile_pre(BpParams& g, hipStream_t stream)
-    {
-        g.ntx = (g.v_dim_x + 63u) / 64u;
-        g.nty = (g.v_dim_y + 15u) / 16u;
-        g.ntz = (g.v_dim_z + g.tz - 1u) / g.tz;
-        settle_order(g);
-        g.zchunk = chunk_tiles(g.order, g.tz, g.ntz, 64u);
-        hipLaunchKernelGGL((bp_column_state_kernel<FD>), dim3((g.v_dim_x + 255u) / 256u, g.v_dim_y), dim3(256), 0, stream, g,
-                           const_cast<float*>(g.colstate));
-        hipLaunchKernelGGL((bp_tile_kernel<4, UNROLL, true, FD, true>), dim3(static_cast<uint32_t>(grid_blocks(g))), dim3(256), g.lds_floats * sizeof(float), stream, g);
-    }
-
-    // ---- slice kernel launchers ------------------------------------------------------------------------------
-    template <int NW, int RPL, bool NT, bool FD>
-    int launch_slice(BpParams& g, uint32_t box_bytes, hipStream_t stream)
-    {
-        constexpr uint32_t TY = 4u * RPL;
-        constexpr uint32_t state_floats = SLICE_STATE_ARRAYS * 64u * TY;
-        g.tz = NW;
-        g.lds_floats = state_floats + box_bytes / sizeof(float);
-        g.ntx = (g.v_dim_x + 63u) / 64u;
-        g.nty = (g.v_dim_y + TY - 1u) / TY;
-        g.ntz = (g.v_dim_z + NW - 1u) / NW;
-        settle_order(g);
-        g.zchunk = chunk_tiles(g.order, NW, g.ntz, 64u);
-        const uint32_t blocks = static_cast<uint32_t>(grid_blocks(g));
-        const uint32_t lds_bytes = g.lds_floats * sizeof(float);
-        if(lds_bytes > 64u * 1024u) // beyond the default dynamic-LDS limit (only with a raised box budget): per launch, cheap
-            PARIS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bp_slice_kernel<NW, RPL, NT, FD>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((bp_slice_kernel<NW, RPL, NT, FD>), dim3(blocks), dim3(NW * 64), lds_bytes, stream, g);
-        return PARIS_HIP_SUCCESS;
-    }
-
-    template <int NW, int RPL>
-    int launch_slice_flags(BpParams& g, uint32_t box_bytes, bool nt, bool fd, hipStream_t stream)
-    {
-        if(nt && fd)
-            return launch_slice<NW, RPL, true, true>(g, box_bytes, stream);
-        if(nt)
-            return launch_slice<NW, RPL, true, false>(g, box_bytes, stream);
-        if(fd)
-            return launch_slice<NW, RPL, false, true>(g, box_bytes, stream);
-        return launch_slice<NW, RPL, false, false>(g, box_bytes, stream);
-    }
-
-    // shape = (waves = slices per tile, row groups per lane); supported: 16x4 16x2 8x4 8x2 8x1
-    int launch_slice_shape(BpParams& g, int nw, int rpl, uint32_t box_bytes, bool nt, bool fd, hipStream_t stream)
-    {
-        if(nw == 16 && rpl == 4) return launch_slice_flags<16, 4>(g, box_bytes, nt, fd, stream);
-        if(nw == 16 && rpl == 2) return launch_slice_flags<16, 2>(g, box_bytes, nt, fd, stream);
-        if(nw == 8 && rpl == 4) return launch_slice_flags<8, 4>(g, box_bytes, nt, fd, stream);
-        if(nw == 8 && rpl == 2) return launch_slice_flags<8, 2>(g, box_bytes, nt, fd, stream);
-        if(nw == 8 && rpl == 1) return launch_slice_flags<8, 1>(g, box_bytes, nt, fd, stream);
-        return PARIS_HIP_ERROR_INVALID_ARGUMENT;
-    }
-
-#endif // PARIS_HIP_EXPERIMENTS
+#ifdef PARIS_HIP_EXPERIMENTS // ... and their launchers
+#include "experiments/bp_launchers.inc"
+#endif
     // Is div_by_constant exact for this divisor? Checked once per process, device and divisor on the GPU (about 2 ms): the
     // result is a property of the divisor, so it is cached process-wide (every ctx of every host thread shares it) and the
     // check runs on a private blocking-free stream of its own -- never on the caller's stream, which may be capturing or may

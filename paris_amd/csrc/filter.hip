@@ -193,229 +193,8 @@ namespace
     // thread), the roots are compile-time constants.
     // ------------------------------------------------------------------------------------------------------------
 #ifdef PARIS_HIP_EXPERIMENTS // the first radix-16 kernel (twiddles formed per stage): superseded by filter_fused.hip; cross-checks and tools only
-    __device__ __forceinline__ float2 root16(int m) // exp(-2 pi i m / 16), m in [0, 8)
-    {
-        constexpr float c[8] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
-                                0.f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
-        constexpr float s[8] = {0.f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
-                                -1.f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
-        return make_float2(c[m], s[m]);
-    }
-
-    __device__ __forceinline__ uint32_t lds_pad(uint32_t i) { return i + (i >> 4); } // one spare slot per 16: no bank conflicts
-
-    // R decimation-in-frequency stages on v[0 .. 2^R): pairs (j, j + Et/2), twiddle base[t] * root(j' * 2^t * 16/E)
-    template <int R>
-    __device__ __forceinline__ void dif_stages(float2 (&v)[1 << R], const float2 (&base)[R])
-    {
-        constexpr int E = 1 << R;
-#pragma unroll
-        for(int t = 0; t < R; ++t)
-        {
-            const int Et = E >> t;
-#pragma unroll
-            for(int j = 0; j < E; ++j)
-            {
-                if((j % Et) < Et / 2)
-                {
-                    const int jp = j % Et;
-                    const float2 w = cmul(base[t], root16(jp * (1 << t) * (16 / E)));
-                    const float2 lo = v[j], hi = v[j + Et / 2];
-                    v[j] = make_float2(lo.x + hi.x, lo.y + hi.y);
-                    v[j + Et / 2] = cmul(make_float2(lo.x - hi.x, lo.y - hi.y), w);
-                }
-            }
-        }
-    }
-
-    // R decimation-in-time inverse stages: pairs (j, j + 2^t), twiddle conj(base[t] * root(j' * 16 / 2^(t+1)))
-    template <int R>
-    __device__ __forceinline__ void dit_stages(float2 (&v)[1 << R], const float2 (&base)[R])
-    {
-        constexpr int E = 1 << R;
-#pragma unroll
-        for(int t = 0; t < R; ++t)
-        {
-            const int span = 1 << t;
-#pragma unroll
-            for(int j = 0; j < E; ++j)
-            {
-                if((j % (2 * span)) < span)
-                {
-                    const int jp = j % span;
-                    float2 w = cmul(base[t], root16(jp * (16 / (2 * span))));
-                    w.y = -w.y;
-                    const float2 lo = v[j];
-                    const float2 c = cmul(v[j + span], w);
-                    v[j] = make_float2(lo.x + c.x, lo.y + c.y);
-                    v[j + span] = make_float2(lo.x - c.x, lo.y - c.y);
-                }
-            }
-        }
-    }
-
-    template <int LOG2N>
-    __global__ void __launch_bounds__((1 << LOG2N) / 16)
-        apply_filter_r16_kernel(float* __restrict__ p, uint32_t pitch_f, uint32_t dim_x, uint32_t dim_y,
-                                const float* __restrict__ k, const float2* __restrict__ tw)
-    {
-        constexpr uint32_t N = 1u << LOG2N;
-        constexpr int NPASS = (LOG2N + 3) / 4;
-        constexpr int RF = LOG2N - 4 * (NPASS - 1); // stages of the first forward / last inverse pass
-        constexpr uint32_t EF = 1u << RF;
-        constexpr uint32_t T = N / 16u;             // threads
-        extern __shared__ __attribute__((aligned(16))) float2 fx[];
-
-        const uint32_t tid = threadIdx.x;
-        const uint32_t row_a = 2u * blockIdx.x;
-        const uint32_t row_b = row_a + 1u;
-        const bool has_b = row_b < dim_y;
-        float* pa = p + static_cast<size_t>(row_a) * pitch_f;
-        float* pb = p + static_cast<size_t>(row_b) * pitch_f;
-
-        // ---- forward, first pass: RF stages on groups {o + j * N/EF}; 16/EF groups per thread; global -> LDS
-#pragma unroll
-        for(uint32_t i = 0; i < 16u / EF; ++i)
-        {
-            const uint32_t o = tid + i * T; // < N / EF
-            float2 v[EF];
-#pragma unroll
-            for(uint32_t j = 0; j < EF; ++j)
-            {
-                const uint32_t idx = o + j * (N / EF);
-                float a = 0.f, b = 0.f; // expand: zero padding beyond the detector row
-                if(idx < dim_x)
-                {
-                    a = pa[idx];
-                    if(has_b)
-                        b = pb[idx];
-                }
-                v[j] = make_float2(a, b);
-            }
-            float2 base[RF];
-#pragma unroll
-            for(int t = 0; t < RF; ++t)
-                base[t] = tw[o << t]; // stage t: W_N^(o * 2^t)
-            dif_stages<RF>(v, base);
-#pragma unroll
-            for(uint32_t j = 0; j < EF; ++j)
-                fx[lds_pad(o + j * (N / EF))] = v[j];
-        }
-        __syncthreads();
-
-        // ---- forward middle passes: 4 stages, block size B = N >> s0
-#pragma unroll
-        for(int pass = 1; pass < NPASS - 1; ++pass)
-        {
-            const uint32_t s0 = static_cast<uint32_t>(RF + 4 * (pass - 1));
-            const uint32_t B = N >> s0;
-            const uint32_t blk = tid / (B / 16u), o = tid % (B / 16u);
-            float2 v[16];
-#pragma unroll
-            for(uint32_t j = 0; j < 16u; ++j)
-                v[j] = fx[lds_pad(blk * B + o + j * (B / 16u))];
-            float2 base[4];
-#pragma unroll
-            for(int t = 0; t < 4; ++t)
-                base[t] = tw[o << (s0 + t)];
-            dif_stages<4>(v, base);
-#pragma unroll
-            for(uint32_t j = 0; j < 16u; ++j)
-                fx[lds_pad(blk * B + o + j * (B / 16u))] = v[j];
-            __syncthreads();
-        }
-
-        // ---- fused pass on 16 contiguous values: last 4 forward stages, K, first 4 inverse stages
-        {
-            float2 v[16];
-#pragma unroll
-            for(uint32_t j = 0; j < 16u; ++j)
-                v[j] = fx[lds_pad(tid * 16u + j)];
-            const float2 one[4] = {make_float2(1.f, 0.f), make_float2(1.f, 0.f), make_float2(1.f, 0.f), make_float2(1.f, 0.f)};
-            dif_stages<4>(v, one);
-#pragma unroll
-            for(uint32_t j = 0; j < 16u; ++j)
-            {
-                const uint32_t f = bit_reverse(tid * 16u + j, LOG2N); // frequency held at this position
-                const float kv = k[f <= N / 2u ? f : N - f];           // do_filtering :92-105, K real and even
-                v[j].x *= kv;
-                v[j].y *= kv;
-            }
-            dit_stages<4>(v, one);
-#pragma unroll
-            for(uint32_t j = 0; j < 16u; ++j)
-                fx[lds_pad(tid * 16u + j)] = v[j];
-        }
-        __syncthreads();
-
-        // ---- inverse middle passes: 4 stages, h0 = 16^pass
-#pragma unroll
-        for(int pass = 1; pass < NPASS - 1; ++pass)
-        {
-            const uint32_t h0 = 1u << (4 * pass);
-            const uint32_t big = tid / h0, o = tid % h0;
-            float2 v[16];
-#pragma unroll
-            for(uint32_t j = 0; j < 16u; ++j)
-                v[j] = fx[lds_pad(big * 16u * h0 + o + j * h0)];
-            float2 base[4];
-#pragma unroll
-            for(int t = 0; t < 4; ++t)
-                base[t] = tw[(o * (N / (2u * h0))) >> t];
-            dit_stages<4>(v, base);
-#pragma unroll
-            for(uint32_t j = 0; j < 16u; ++j)
-                fx[lds_pad(big * 16u * h0 + o + j * h0)] = v[j];
-            __syncthreads();
-        }
-
-        // ---- inverse last pass: RF stages on groups {o + j * N/EF}; shrink + normalize + store
-        const float n_f = static_cast<float>(N);
-#pragma unroll
-        for(uint32_t i = 0; i < 16u / EF; ++i)
-        {
-            const uint32_t o = tid + i * T;
-            constexpr uint32_t h0 = N / EF;
-            float2 v[EF];
-#pragma unroll
-            for(uint32_t j = 0; j < EF; ++j)
-                v[j] = fx[lds_pad(o + j * h0)];
-            float2 base[RF];
-#pragma unroll
-            for(int t = 0; t < RF; ++t)
-                base[t] = tw[(o * (EF / 2u)) >> t];
-            dit_stages<RF>(v, base);
-#pragma unroll
-            for(uint32_t j = 0; j < EF; ++j)
-            {
-                const uint32_t idx = o + j * h0;
-                if(idx < dim_x)
-                {
-                    pa[idx] = v[j].x / n_f;
-                    if(has_b)
-                        pb[idx] = v[j].y / n_f;
-                }
-            }
-        }
-    }
-
-    template <int LOG2N>
-    int launch_r16(paris_hip_ctx* ctx, float* d_p, uint32_t pitch_f, uint32_t dim_x, uint32_t dim_y, const float* d_k, const float2* tw)
-    {
-        constexpr uint32_t N = 1u << LOG2N;
-        constexpr uint32_t lds_bytes = (N + N / 16u) * sizeof(float2);
-        if(lds_bytes > 64u * 1024u && !ctx->filter_r16_attr_set[LOG2N - 10])
-        {
-            PARIS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(apply_filter_r16_kernel<LOG2N>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-            ctx->filter_r16_attr_set[LOG2N - 10] = true;
-        }
-        hipLaunchKernelGGL((apply_filter_r16_kernel<LOG2N>), dim3((dim_y + 1u) / 2u), dim3(N / 16u), lds_bytes, ctx->stream, d_p,
-                           pitch_f, dim_x, dim_y, d_k, tw);
-        return PARIS_HIP_SUCCESS;
-    }
-
-#endif // PARIS_HIP_EXPERIMENTS
+#include "experiments/filter_r16.inc"
+#endif
 
     inline bool is_pow2(uint32_t v) { return v != 0 && (v & (v - 1)) == 0; }
 
