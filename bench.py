@@ -492,13 +492,35 @@ def launch_ranks(args, argv):
     sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
     sys.stderr.flush()
     child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)  # (stderr is inherited)
-    line = None
-    for text in child.stdout:
-        if text.startswith("{"):
-            line = text
-        elif text.strip():
-            sys.stderr.write(text)
+    import threading
+    seen = {"line": None, "at": None}
+
+    def relay():
+        for text in child.stdout:
+            if text.startswith("{"):
+                seen["line"], seen["at"] = text, time.perf_counter()
+            elif text.strip():
+                sys.stderr.write(text)
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    # the line is the result: ranks that do not come down after it (a hang while the process group is torn down) must not cost the
+    # caller its own time limit
+    while child.poll() is None:
+        if seen["at"] is not None and time.perf_counter() - seen["at"] > 120.0:
+            sys.stderr.write("bench.py: the ranks did not exit within 120 s of the result line: terminating them\n")
+            child.terminate()
+            try:
+                child.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                child.kill()
+            break
+        time.sleep(0.2)
     rc = child.wait()
+    reader.join(timeout=5)
+    line = seen["line"]
+    if line is not None and rc != 0 and seen["at"] is not None and time.perf_counter() - seen["at"] > 120.0:
+        rc = 0  # (the measurement was complete; only the teardown was cut short)
     if line is not None:
         sys.stdout.write(line if line.endswith("\n") else line + "\n")
         sys.stdout.flush()
