@@ -327,6 +327,7 @@ def test_default_run_reports_every_baseline_config():
     for key, e in pl.items():
         assert "error" not in e, (key, e)
         assert e["value"] > 0 and e["seconds"] > 0 and e["unit"] == "GVoxel-updates/s" and e["deferral"] == 48
+        assert e["by_reference"] == 1 and e["filter_deferral"] == 2   # the mirror's defaults since round 5
         assert 0.0 <= e["host_fill_share"] < 1.0 and 0.0 < e["backend_call_share"] < 1.0 and "second" in e["streams"]
         assert abs(e["value"] - float(e["volume"][0]) * e["volume"][1] * e["volume"][2] * e["projections"] / e["seconds"] / 1e9) < 1e-3 * e["value"]
         assert sorted(e["us_per_projection"]) == ["backproject", "filter", "frame_fill", "free_device", "free_host", "load",
