@@ -1107,6 +1107,11 @@ def main():
         if dist is not None:
             out["config"]["rank_placement"] = placement
             out["config"]["per_rank"] = per_rank
+            # what this line does NOT contain: the ranks' frames are resident in HBM before the timed region, as the
+            # contract asks -- no host frame fill, no upload. PARIS's own loop (fill + upload per projection, host bound at the slab
+            # shape of 8 ranks: 0.55 ms of fill per 16 MiB frame) is measured at N = 1 (`paris_loop`); N such loops on one host would
+            # share its memory bandwidth, which a one-GPU box cannot show
+            out["config"]["frames"] = "resident in HBM on every rank before the timed region (no host fill, no upload in this line)"
             # the PMC traffic figure is of ONE kernel build: every rank reports the build it ran
             out["roofline"]["kernel_source_sha16_by_rank"] = [r["kernel_source_sha16"] for r in per_rank]
         mark("final_gather_and_report")
