@@ -416,6 +416,18 @@ class Backend:
         check(self._L.paris_hip_projection_reserve_bytes(self._ctx, dim_x, dim_y, C.byref(n)), "paris_hip_projection_reserve_bytes")
         return int(n.value)
 
+    def set_paris_loop_defaults(self, depth=48):
+        """The settings the C++ mirror paris::hip makes in set_device() (paris_amd/host/paris/hip/backend.h) for PARIS's own loop --
+        a buffer allocated, filled, weighted, filtered, backprojected and freed per projection (src/main.cpp:98-105): stage fusion,
+        `depth` backprojections per fused launch on the second stream, projections by reference, the filter in place a group at a
+        time, validators beside the first projections. Every result stays bit-identical; needs an asynchronous backend."""
+        self.set_stage_fusion(True)
+        self.set_backproject_deferral(depth)
+        self.set_backproject_overlap(True)
+        self.set_backproject_references(True)
+        self.set_filter_deferral(2)
+        self.set_async_validation(True)
+
     def flush(self):
         check(self._L.paris_hip_flush(self._ctx), "paris_hip_flush")
 

@@ -287,10 +287,7 @@ def test_asynchronous_validation_changes_no_bit(oracle):
 
     def run(asynchronous, raw):
         with B.Backend(0, synchronous=False) as abe:
-            abe.set_stage_fusion(True)
-            abe.set_backproject_deferral(4)
-            abe.set_backproject_references(True)
-            abe.set_filter_deferral(2)
+            abe.set_paris_loop_defaults(depth=4)      # what paris::hip's set_device() switches on
             abe.set_async_validation(asynchronous)
             d_v = abe.make_volume_device(vg.dim_x, vg.dim_y, vg.dim_z)
             for i in range(n_proj):
