@@ -191,14 +191,18 @@ int main(int argc, char** argv)
         if(json)
         {
             const double per = 1e6 / (static_cast<double>(n_proj) * info.num);
+            // what the device holds when the loops are over (the last slab's volume has been released by now): the library's parked
+            // projection buffers and tables -- bounded, however many projections went through
+            std::size_t mem_free = 0, mem_total = 0;
+            (void)paris_hip_device_memory(devices[0], &mem_free, &mem_total);
             std::printf("{\"volume\": [%u, %u, %u], \"projections\": %u, \"frame\": [%u, %u], \"slabs\": %d, \"seconds\": %.6f, \"value\": %.3f, "
                         "\"unit\": \"GVoxel-updates/s\", \"host_fill_seconds\": %.6f, \"backend_call_seconds\": %.6f, \"final_wait_seconds\": %.6f, "
-                        "\"deferral\": %d, \"streams\": \"%s\", \"filter_deferral\": %d, \"by_reference\": %d, \"us_per_projection\": {\"make_projection_host\": %.3f, "
+                        "\"deferral\": %d, \"streams\": \"%s\", \"filter_deferral\": %d, \"by_reference\": %d, \"device_bytes_in_use_after_the_loops\": %zu, \"us_per_projection\": {\"make_projection_host\": %.3f, "
                         "\"frame_fill\": %.3f, \"load\": %.3f, \"weight\": %.3f, \"filter\": %.3f, \"backproject\": %.3f, \"free_device\": %.3f, "
                         "\"free_host\": %.3f}}\n", roi_geo.dim_x, roi_geo.dim_y, roi_geo.dim_z, n_proj, det.n_row, det.n_col, info.num, loop_s,
                         static_cast<double>(roi_geo.dim_x) * roi_geo.dim_y * roi_geo.dim_z * n_proj / loop_s / 1e9, fill_s, loop_s - fill_s - tail_s, tail_s,
                         PARIS_HIP_BACKPROJECT_DEFERRAL, PARIS_HIP_BACKPROJECT_OVERLAP ? "compute + second (fused launches) + upload" : "one",
-                        PARIS_HIP_FILTER_DEFERRAL, PARIS_HIP_BACKPROJECT_REFERENCES, split_s[0] * per, split_s[1] * per, split_s[2] * per, split_s[3] * per, split_s[4] * per,
+                        PARIS_HIP_FILTER_DEFERRAL, PARIS_HIP_BACKPROJECT_REFERENCES, mem_total - mem_free, split_s[0] * per, split_s[1] * per, split_s[2] * per, split_s[3] * per, split_s[4] * per,
                         split_s[5] * per, split_s[6] * per, split_s[7] * per);
         }
         return 0;

@@ -159,3 +159,22 @@ def test_flush_rules_at_config3_size():
     assert r.returncode == 0, r.stdout + r.stderr
     # four read-backs of the deferred run + three of the run with the fused launches on the ctx's second stream
     assert "flush rules ok" in r.stdout and r.stdout.count("equal bit for bit") == 7 and r.stdout.count("second stream") == 3
+
+
+def test_cpp_loop_device_memory_is_bounded_by_the_rotation(tmp_path):
+    """ADVICE r04 / deferral by reference: however many projections PARIS's loop pushes through paris::hip, what the device holds
+    afterwards is the library's bounded rotation of projection buffers (two groups of 48 and a few, here 4 MiB frames) and its
+    tables -- the same after 300 projections as after 2400 (paris_hip_demo --json reports the bytes in use once the loops are over
+    and the volume has been released)."""
+    import json
+    seen = []
+    for n_proj in (300, 2400):
+        r = subprocess.run([DEMO, "1024", "1024", "0.2", "0.2", "0", "0", "500", "500", "0.15", str(n_proj), "lcg", "/dev/null", "--cycle", "16",
+                            "--no-out", "--json", "--vol", "512", "512", "256", "0.2"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["by_reference"] == 1 and d["projections"] == n_proj
+        seen.append(d["device_bytes_in_use_after_the_loops"])
+    frame = 1024 * 1024 * 4
+    assert abs(seen[1] - seen[0]) <= 16 * frame, seen          # no growth with the number of projections
+    assert seen[1] <= (2 << 30), seen                          # runtime + tables + at most 104 parked frames of 4 MiB
