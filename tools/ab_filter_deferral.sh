@@ -1,4 +1,6 @@
-# A/B of PARIS_HIP_FILTER_DEFERRAL in the C++ mirror (0 = paris_hip_demo, the default, against 1 = paris_hip_demo_filter_deferral), PARIS's
+# A/B of PARIS_HIP_FILTER_DEFERRAL in the C++ mirror. Round 4 (profiles/r04_ab_filter_deferral_in_the_mirror.txt): 0 = paris_hip_demo, then the
+# default, against 1 = paris_hip_demo_filter_deferral. Since round 5 the default is 2 (held back only where the filter can run in place, by
+# reference) and paris_hip_demo_filter_at_once is the 0 build: tools/mirror_split.sh compares those. PARIS's
 # per-projection loop, whole circles: natural volumes of 512^2 / 1024^2 / 2048^2 detectors, the 2048 x 2048 x 256 slab a rank of the 8-GPU
 # configuration owns (2048^2 frames), and BASELINE config 1 (256^3 from 512^2 frames)
 D=paris_amd/host/demo
