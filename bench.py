@@ -467,7 +467,7 @@ def octant_stats(kernel_ms, idx_of_launch, n_proj):
     return out
 
 
-def launch_ranks(args, argv):
+def launch_ranks(args, argv, grace=120.0, _cmd=None):
     """`python3 bench.py --gpus N` with N > 1 and no RANK in the environment: the job starts itself. One rank per GPU is started
     through torch.distributed.run as an ordinary CHILD process (this process never touches the GPU: counting devices does not
     initialise it, and nothing is exec'ed), rank 0's one JSON line is relayed to stdout, the launcher's exit status is returned.
@@ -475,7 +475,7 @@ def launch_ranks(args, argv):
     import socket
     import subprocess
     n = args.gpus
-    if args.dist_backend == "nccl":
+    if _cmd is None and args.dist_backend == "nccl":
         import torch
         visible = torch.cuda.device_count()
         if visible < n:
@@ -489,6 +489,8 @@ def launch_ranks(args, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes fails without it on this driver
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--max-restarts", "0",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if _cmd is not None:  # (tests: another child in the launcher's place)
+        cmd = list(_cmd)
     sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
     sys.stderr.flush()
     child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)  # (stderr is inherited)
@@ -507,8 +509,8 @@ def launch_ranks(args, argv):
     # the line is the result: ranks that do not come down after it (a hang while the process group is torn down) must not cost the
     # caller its own time limit
     while child.poll() is None:
-        if seen["at"] is not None and time.perf_counter() - seen["at"] > 120.0:
-            sys.stderr.write("bench.py: the ranks did not exit within 120 s of the result line: terminating them\n")
+        if seen["at"] is not None and time.perf_counter() - seen["at"] > grace:
+            sys.stderr.write("bench.py: the ranks did not exit within %.0f s of the result line: terminating them\n" % grace)
             child.terminate()
             try:
                 child.wait(timeout=15)
@@ -519,7 +521,7 @@ def launch_ranks(args, argv):
     rc = child.wait()
     reader.join(timeout=5)
     line = seen["line"]
-    if line is not None and rc != 0 and seen["at"] is not None and time.perf_counter() - seen["at"] > 120.0:
+    if line is not None and rc != 0 and seen["at"] is not None and time.perf_counter() - seen["at"] > grace:
         rc = 0  # (the measurement was complete; only the teardown was cut short)
     if line is not None:
         sys.stdout.write(line if line.endswith("\n") else line + "\n")
