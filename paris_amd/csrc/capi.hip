@@ -1136,8 +1136,12 @@ extern "C" int paris_hip_memcpy_projection_h2d(paris_hip_ctx* ctx, float* d_dst,
         return PARIS_HIP_ERROR_INVALID_ARGUMENT;
     if(int rc = paris_hip_projection_guard(ctx, d_dst, d_pitch * dim_y, ctx->stream, true))
         return rc;
-    PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
-                                   hipMemcpyHostToDevice, ctx->stream));
+    // rows as far apart on both sides as they are long: one linear copy (the 2-D form costs the runtime more per call)
+    if(d_pitch == h_pitch && d_pitch == static_cast<size_t>(dim_x) * sizeof(float))
+        PARIS_HIP_TRY(hipMemcpyAsync(d_dst, h_src, d_pitch * dim_y, hipMemcpyHostToDevice, ctx->stream));
+    else
+        PARIS_HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, static_cast<size_t>(dim_x) * sizeof(float), dim_y,
+                                       hipMemcpyHostToDevice, ctx->stream));
     paris_hip_note_host_use(ctx, h_src, paris_hip_ctx::USED_COMPUTE);
     if(int rc = paris_hip_note_projection_use(ctx, d_dst, d_pitch * dim_y)) // a later upload into the buffer must not overtake this copy
         return rc;

@@ -179,7 +179,9 @@ int main(int argc, char** argv)
         std::printf("ok %u %u %u\n", roi_geo.dim_x, roi_geo.dim_y, roi_geo.dim_z);
         std::printf("projection loops %.3f s: %.1f GVoxel-updates/s through paris::load / weight / filter / backproject (deferral depth %d, %s)\n", loop_s,
                     static_cast<double>(roi_geo.dim_x) * roi_geo.dim_y * roi_geo.dim_z * n_proj / loop_s / 1e9, PARIS_HIP_BACKPROJECT_DEFERRAL,
-                    PARIS_HIP_BACKPROJECT_OVERLAP ? "fused launches on the second stream, uploads on the upload stream" : "one stream");
+                    PARIS_HIP_BACKPROJECT_OVERLAP ? (PARIS_HIP_UPLOAD_ON_ITS_OWN_STREAM ? "fused launches on the second stream, uploads on the upload stream"
+                                                                                         : "fused launches on the second stream, uploads on the compute stream")
+                                                  : "one stream");
         std::printf("of which: host frame fill (memcpy into the pinned buffer) %.3f s, backend calls %.3f s, final wait for the GPU %.3f s\n", fill_s,
                     loop_s - fill_s - tail_s, tail_s);
         {
@@ -201,7 +203,7 @@ int main(int argc, char** argv)
                         "\"frame_fill\": %.3f, \"load\": %.3f, \"weight\": %.3f, \"filter\": %.3f, \"backproject\": %.3f, \"free_device\": %.3f, "
                         "\"free_host\": %.3f}}\n", roi_geo.dim_x, roi_geo.dim_y, roi_geo.dim_z, n_proj, det.n_row, det.n_col, info.num, loop_s,
                         static_cast<double>(roi_geo.dim_x) * roi_geo.dim_y * roi_geo.dim_z * n_proj / loop_s / 1e9, fill_s, loop_s - fill_s - tail_s, tail_s,
-                        PARIS_HIP_BACKPROJECT_DEFERRAL, PARIS_HIP_BACKPROJECT_OVERLAP ? "compute + second (fused launches) + upload" : "one",
+                        PARIS_HIP_BACKPROJECT_DEFERRAL, PARIS_HIP_BACKPROJECT_OVERLAP ? (PARIS_HIP_UPLOAD_ON_ITS_OWN_STREAM ? "compute + second (fused launches) + upload" : "compute (copies) + second (filter, fused launches)") : "one",
                         PARIS_HIP_FILTER_DEFERRAL, PARIS_HIP_BACKPROJECT_REFERENCES, mem_total - mem_free, split_s[0] * per, split_s[1] * per, split_s[2] * per, split_s[3] * per, split_s[4] * per,
                         split_s[5] * per, split_s[6] * per, split_s[7] * per);
         }

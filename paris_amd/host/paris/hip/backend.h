@@ -56,6 +56,17 @@
 #define PARIS_HIP_BACKPROJECT_REFERENCES 1
 #endif
 
+// Which stream copy_h2d(projection) runs on. 1: the ctx's upload stream (paris_hip_upload_projection; the compute stream is ordered
+// behind every copy by an event pair, ~2.3 us of runtime calls per frame): what the loop needs when kernels of its own -- a filter
+// per projection, snapshot copies -- share the compute stream with the copies. 0: the compute stream itself. Default: 0 when the
+// projections are taken by reference and filtered in place a group at a time (PARIS_HIP_BACKPROJECT_REFERENCES with
+// PARIS_HIP_FILTER_DEFERRAL 2): the loop then enqueues NOTHING but its copies on the compute stream -- the group's filter and fused
+// launch run on the second stream, ordered behind the copies by the one event each launch records anyway -- so a stream of their own
+// buys the copies nothing and costs the event pair; 1 otherwise.
+#ifndef PARIS_HIP_UPLOAD_ON_ITS_OWN_STREAM
+#define PARIS_HIP_UPLOAD_ON_ITS_OWN_STREAM (PARIS_HIP_BACKPROJECT_OVERLAP && !(PARIS_HIP_BACKPROJECT_REFERENCES && PARIS_HIP_FILTER_DEFERRAL == 2 && PARIS_HIP_BACKPROJECT_DEFERRAL > 1))
+#endif
+
 #include <cstddef>
 #include <cstdint>
 #include <map>
@@ -243,9 +254,10 @@ namespace paris
 
         inline auto copy_h2d(const projection_host_type& h_p, projection_device_type& d_p) -> void
         {
-            // on the upload stream when overlapping: the transfer does not wait behind kernels queued on the compute stream, and
-            // the pinned source is released when this copy is done (the compute stream is ordered behind the copy by the library)
-            detail::runtime_check((PARIS_HIP_BACKPROJECT_OVERLAP && !PARIS_HIP_SYNCHRONOUS_CALLS ? paris_hip_upload_projection : paris_hip_memcpy_projection_h2d)(
+            // on the upload stream when the loop's own kernels share the compute stream: the transfer does not wait behind them, and
+            // the pinned source is released when this copy is done (the compute stream is ordered behind the copy by the library);
+            // on the compute stream when nothing else is enqueued there (PARIS_HIP_UPLOAD_ON_ITS_OWN_STREAM above)
+            detail::runtime_check((PARIS_HIP_UPLOAD_ON_ITS_OWN_STREAM && !PARIS_HIP_SYNCHRONOUS_CALLS ? paris_hip_upload_projection : paris_hip_memcpy_projection_h2d)(
                                       current_ctx(), d_p.buf.get(), d_p.buf.pitch(), h_p.buf.get(), std::size_t{h_p.dim_x} * sizeof(float), h_p.dim_x, h_p.dim_y),
                                   "copy_h2d(projection)");
             d_p.idx = h_p.idx; // src/openmp/memory.cpp:60-62
