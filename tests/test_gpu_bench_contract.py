@@ -243,13 +243,20 @@ def test_config3_line_measures_its_traffic_in_the_run():
     assert fr["source"].startswith("measured in this run") and 15.0 < fr["valu_instructions_per_voxel_update"] < 40.0
 
 
-def _torchrun(n, extra, timeout=1500):
+def _torchrun(n, extra, timeout=1500, plain=False):
+    """N ranks of bench.py: started by torch.distributed.run (the driver's way for N > 1), or -- plain=True -- by bench.py's own
+    launcher from the plain command line (`python bench.py --gpus N ...`, no RANK in the environment)"""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + extra,
-                       capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    if plain:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + extra, capture_output=True, text=True,
+                           timeout=timeout, cwd=ROOT, env=env)
+    else:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+                            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + extra,
+                           capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     return last_json_line(r.stdout)
 
@@ -272,8 +279,9 @@ def test_eight_slab_partition_at_full_shape(workload, gather):
     assert len(want) == 8 and all(abs(v) > 0 for v in want)
     got, bands = [], []
     for base in (0, 4):
+        # (the second wave through bench.py's own launcher: the plain command line at full shape)
         d = _torchrun(4, common + ["--dist-backend", "gloo", "--device", "0", "--final-gather", gather, "--as-world", "8",
-                                   "--as-rank-base", str(base)])
+                                   "--as-rank-base", str(base)], plain=(base == 4))
         pr = d["config"]["per_rank"]
         assert [e["as_rank"] for e in pr] == [base + r for r in range(4)]
         assert [e["slab"] for e in pr] == [[256 * (base + r), 256] for r in range(4)]
