@@ -60,11 +60,13 @@
 // behind every copy by an event pair, ~2.3 us of runtime calls per frame): what the loop needs when kernels of its own -- a filter
 // per projection, snapshot copies -- share the compute stream with the copies. 0: the compute stream itself. Default: 0 when the
 // projections are taken by reference and filtered in place a group at a time (PARIS_HIP_BACKPROJECT_REFERENCES with
-// PARIS_HIP_FILTER_DEFERRAL 2): the loop then enqueues NOTHING but its copies on the compute stream -- the group's filter and fused
+// PARIS_HIP_FILTER_DEFERRAL 2, which needs PARIS_HIP_STAGE_FUSION): the loop then enqueues NOTHING but its copies on the compute stream -- the group's filter and fused
 // launch run on the second stream, ordered behind the copies by the one event each launch records anyway -- so a stream of their own
 // buys the copies nothing and costs the event pair; 1 otherwise.
 #ifndef PARIS_HIP_UPLOAD_ON_ITS_OWN_STREAM
-#define PARIS_HIP_UPLOAD_ON_ITS_OWN_STREAM (PARIS_HIP_BACKPROJECT_OVERLAP && !(PARIS_HIP_BACKPROJECT_REFERENCES && PARIS_HIP_FILTER_DEFERRAL == 2 && PARIS_HIP_BACKPROJECT_DEFERRAL > 1))
+#define PARIS_HIP_UPLOAD_ON_ITS_OWN_STREAM                                                                                        \
+    (PARIS_HIP_BACKPROJECT_OVERLAP                                                                                               \
+     && !(PARIS_HIP_BACKPROJECT_REFERENCES && PARIS_HIP_FILTER_DEFERRAL == 2 && PARIS_HIP_STAGE_FUSION && PARIS_HIP_BACKPROJECT_DEFERRAL > 1))
 #endif
 
 #include <cstddef>
